@@ -1,0 +1,83 @@
+"""Seeded synthetic inputs for the front-end path (frames, SuperPoint weights).
+
+The reference ships no weights and no dataset (/sly_slam/superpoint_new.pt is a
+hard-coded path to a file that was never committed, /root/reference/src/SPextractor.cpp:86), so every
+test and benchmark in this repo runs on the deterministic synthetic inputs defined here
+(SURVEY.md section 8d).  Pure numpy, no torch: the same bytes are produced here and on the GPU box.
+
+Weight tensors use the reference's own parameter names and OIHW layout
+(`conv1a.weight` ... `convDb.bias`, /root/reference/src/SuperPoint.cpp:16-52) so that real weights
+converted with tools/convert_weights.py drop into the same loader.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# (name, Cin, Cout, ksize) in forward order -- /root/reference/src/SuperPoint.cpp:16-33
+SP_LAYERS = [
+    ("conv1a", 1, 64, 3), ("conv1b", 64, 64, 3),
+    ("conv2a", 64, 64, 3), ("conv2b", 64, 64, 3),
+    ("conv3a", 64, 128, 3), ("conv3b", 128, 128, 3),
+    ("conv4a", 128, 128, 3), ("conv4b", 128, 128, 3),
+    ("convPa", 128, 256, 3), ("convPb", 256, 65, 1),
+    ("convDa", 128, 256, 3), ("convDb", 256, 256, 1),
+]
+
+
+def superpoint_weights(seed: int = 0, pb_gain: float = 3.0, dustbin_bias: float = 9.5) -> dict:
+    """He-uniform weights (variance preserving through the ReLU stack) + small biases.
+
+    `pb_gain` / `dustbin_bias` shape the detector head so that the 65-way softmax is peaky enough for
+    roughly 1-3 k pixels of a synthetic 640x480 frame to exceed the reference's iniTh=0.015
+    (Examples/RGB-D/TUM3.yaml:42-55); with an untrained flat head every pixel would sit at 1/65=0.0154.
+    """
+    rng = np.random.RandomState(seed)
+    w = {}
+    for name, cin, cout, k in SP_LAYERS:
+        fan_in = cin * k * k
+        bound = np.sqrt(6.0 / fan_in)
+        w[name + ".weight"] = rng.uniform(-bound, bound, size=(cout, cin, k, k)).astype(np.float32)
+        w[name + ".bias"] = rng.uniform(-0.05, 0.05, size=(cout,)).astype(np.float32)
+    w["convPb.weight"] = (w["convPb.weight"] * np.float32(pb_gain)).astype(np.float32)
+    w["convPb.bias"][64] += np.float32(dustbin_bias)
+    return w
+
+
+def _blur_axis(a: np.ndarray, k: np.ndarray, axis: int) -> np.ndarray:
+    r = len(k) // 2
+    pad = [(0, 0), (0, 0)]
+    pad[axis] = (r, r)
+    ap = np.pad(a, pad, mode="reflect")
+    out = np.zeros_like(a)
+    n = a.shape[axis]
+    for i, kv in enumerate(k):          # fixed summation order -> identical bits everywhere
+        sl = [slice(None), slice(None)]
+        sl[axis] = slice(i, i + n)
+        out = out + kv * ap[tuple(sl)]
+    return out
+
+
+def frame(i: int, width: int = 640, height: int = 480) -> np.ndarray:
+    """Synthetic grayscale frame i (uint8 [H, W]): band-limited noise (sigma=2 px Gaussian blur of
+    uniform noise, contrast-stretched) plus 200 random axis-aligned rectangles."""
+    rng = np.random.RandomState(1234 + i)
+    noise = rng.uniform(0.0, 1.0, size=(height, width))
+    xs = np.arange(-6, 7, dtype=np.float64)
+    k = np.exp(-(xs * xs) / (2.0 * 2.0 * 2.0))
+    k = k / k.sum()
+    img = _blur_axis(_blur_axis(noise, k, 0), k, 1)
+    img = (img - img.min()) / (img.max() - img.min())
+    img = 0.25 + 0.5 * img
+    for _ in range(200):
+        w = int(rng.randint(6, 60)); h = int(rng.randint(6, 60))
+        x = int(rng.randint(0, width - w)); y = int(rng.randint(0, height - h))
+        v = float(rng.uniform(0.0, 1.0))
+        img[y:y + h, x:x + w] = 0.6 * v + 0.4 * img[y:y + h, x:x + w]
+    return np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8)
+
+
+def frame_bgr(i: int, width: int = 640, height: int = 480) -> np.ndarray:
+    """BGR variant for the YOLO detector: the same pattern with a per-channel gain."""
+    g = frame(i, width, height).astype(np.float64)
+    gains = (0.9, 1.0, 0.8)
+    return np.stack([np.clip(np.rint(g * s), 0, 255) for s in gains], axis=-1).astype(np.uint8)
