@@ -1,0 +1,93 @@
+// Internal declarations shared by the HIP kernels and the engine (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+namespace dani {
+
+// ---------------------------------------------------------------------------------------------
+// Activation layout in HBM: "padded planar" f32  [B][C][Hp][Wp].
+// Pixel (y, x) of channel c lives at row y + PADY, column x + PADX.  The border (row 0, columns
+// 0..3, and everything right of W / below H) is zeroed once at allocation and never written, so the
+// 3x3 halo loads of the conv kernels need no bounds checks and read the literal zeros of "same"
+// padding; PADX = 4 keeps the interior and the halo loads 16-byte aligned.
+// ---------------------------------------------------------------------------------------------
+constexpr int PADX = 4;
+constexpr int PADY = 1;
+
+struct ActDesc {
+  float* p = nullptr;
+  int C = 0, H = 0, W = 0;  // logical dims
+  int Hp = 0, Wp = 0;       // padded plane dims
+  size_t frame_stride() const { return (size_t)C * Hp * Wp; }
+  size_t bytes(int B) const { return frame_stride() * B * sizeof(float); }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline void act_shape(ActDesc& a, int C, int H, int W) {
+  a.C = C; a.H = H; a.W = W;
+  a.Hp = PADY + round_up(H, 16) + 1;      // tiles are at most 16 rows tall
+  a.Wp = PADX + round_up(W, 32) + 4;      // tiles are at most 32 columns wide; +4 right halo
+}
+
+// Which conv kernel variant a layer uses (see conv_mfma.hip).
+enum ConvVariant {
+  CONV3_ROW32_RELU = 0,       // 3x3, wave = 2 rows x 32 cols, WG tile 8x32, 64 couts, ReLU
+  CONV3_ROW32_RELU_POOL = 1,  // same + fused 2x2 max-pool
+  CONV3_BLK16_RELU = 2,       // 3x3, wave = 4 rows x 16 cols, WG tile 16x16, 64 couts, ReLU (1/8-res layers)
+  CONV1_BLK16_LINEAR = 3,     // 1x1, WG tile 16x16, 64 couts, no activation
+};
+
+struct ConvLayerPlan {
+  ConvVariant variant;
+  int Cin, Cout, ksize;
+  int cout_tiles;        // ceil(Cout / 64)
+  int CC;                // input channels per LDS chunk
+  float* w_packed = nullptr;  // device, [cout_tile][chunk][cp][tap][cc][64]
+  float* bias_packed = nullptr;  // device, cout_tiles * 64
+  size_t w_packed_floats = 0;
+};
+
+// host-side packing of OIHW weights into the kernel layout
+void pack_conv_weights(const float* w_oihw, const float* bias, int Cin, int Cout, int ksize, int CC, int NCO,
+                       float* w_packed, float* bias_packed);
+inline int conv_variant_cc(ConvVariant v) { return v == CONV1_BLK16_LINEAR ? 32 : 8; }
+
+// ---- kernel launchers (all asynchronous on `s`) ------------------------------------------------
+// conv1a: u8 image -> 64-channel padded planar, fused /255 + 3x3 conv + bias + ReLU (VALU kernel).
+void launch_conv1a(const uint8_t* img, int B, int H, int W, int stride, size_t img_frame_stride, const float* w /*64*9*/,
+                   const float* bias /*64*/, const ActDesc& out, hipStream_t s);
+void launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s);
+const char* conv_kernel_name(ConvVariant v);
+
+// semi [B][65(+pad)][..] padded planar -> prob [B][PH][PW] dense
+void launch_softmax_d2s(const ActDesc& semi, float* prob, int B, hipStream_t s);
+// desc raw padded planar [B][256][..] -> normalised NHWC [B][Hc*Wc][256] (+ optional dense NCHW copy for tests)
+void launch_desc_norm(const ActDesc& desc, float* desc_nhwc, float* desc_nchw_opt, int B, hipStream_t s);
+
+struct CellRect { int iniX, maxX, iniY, maxY, offX, offY; };
+constexpr int CELL_MAX_DIM = 64;  // a cell is at most 64 x 64 pixels (one lane per column)
+// per-cell threshold + NMS2 (Q4 semantics) + dynamic-box cull -> per-cell slots + counts
+void launch_cell_nms(const float* prob, int PH, int PW, int B, const CellRect* cells, int ncells, float iniTh,
+                     float minTh, const int32_t* boxes, const int32_t* box_offsets, int minBorder, float* slot_xyr,
+                     int32_t* slot_count, int slot_stride, hipStream_t s);
+// ordered compaction of the per-cell slots -> cand [B][cand_cap][3], cand_count[B]
+void launch_cell_compact(const float* slot_xyr, const int32_t* slot_count, int ncells, int slot_stride, int B,
+                         float* cand_xyr, int32_t* cand_count, int cand_cap, hipStream_t s);
+// bilinear sampling (grid_sampler, align_corners=false) + per-channel norm over keypoints (Q7)
+void launch_descriptors(const float* desc_nhwc, int Hc, int Wc, int PH, int PW, const float* kxy /*[B][cap][2]*/,
+                        const int32_t* nk /*[B] device*/, int B, int cap, float* sampled /*[B][cap][256]*/,
+                        float* out /*[B][cap][256]*/, hipStream_t s);
+void launch_copy_layer_dense(const ActDesc& a, int b, float* out_dense, hipStream_t s);
+
+// ---- host logic --------------------------------------------------------------------------------
+struct HostKey { float x, y, r; };
+// DistributeOctTree (reference src/SPextractor.cpp:405-629); returns indices into `keys`, in list order.
+void distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY, int maxY, int N,
+                        std::vector<int>& out_idx);
+int cell_grid(int width, int height, std::vector<CellRect>& cells);
+void features_per_level(int nfeatures, float scaleFactor, int nlevels, std::vector<int>& per_level,
+                        std::vector<float>& scales);
+
+}  // namespace dani

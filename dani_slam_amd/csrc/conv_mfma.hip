@@ -1,0 +1,279 @@
+// conv_mfma.hip -- implicit-GEMM convolutions on the gfx950 FP32 matrix cores.
+//
+// Replaces the 11 MFMA-shaped Conv2d layers of SuperPoint::forward
+// (/root/reference/src/SuperPoint.cpp:16-33 definitions, :58-77 use; LibTorch-CPU conv in the reference).
+//
+// GEMM view:  D[cout][pixel] = sum_k  W[cout][k] * X[k][pixel],   k = (cin-pair cp, ky, kx, cc)
+//   A operand (32 rows)  = weights,  lane l holds W[cout = l&31][k = l>>5]
+//   B operand (32 cols)  = pixels,   lane l holds X[k = l>>5][pixel = l&31]
+// One v_mfma_f32_32x32x2_f32 therefore consumes input channels (2cp, 2cp+1) of one filter tap.  The
+// instruction is bit-for-bit an ordered fmaf chain (tools/probes/mfma_chain_probe.hip), so walking k in
+// the order (cp, ky, kx, cc) with the accumulator initialised to the bias reproduces the repo's canonical
+// f32 evaluation order exactly (oracle/sp_oracle.cpp orc_conv2d).  No split-K, no
+// re-association anywhere: the output is bit-identical to the oracle.
+//
+// Work decomposition: a workgroup = 4 waves = 64 couts x (TH x TW) pixels of one frame; each wave owns
+// 2 cout blocks x NPB pixel blocks of 32 pixels (4 independent 32x32 accumulators = 64 VGPRs).  Input
+// channels are streamed through LDS in chunks of CC channels (haloed tile + the matching weight slab);
+// the next chunk is prefetched global->VGPR while the current one feeds the MFMAs, and 2-4 workgroups
+// per CU cover each other's barriers.  Roofline: MFMA-bound (arithmetic intensity of a tile is ~80 FLOP/B
+// against L2, >1000 FLOP/B against HBM).
+#include "common.h"
+
+namespace dani {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* in;
+  const float* w;      // packed
+  const float* bias;   // packed
+  float* out;
+  int Cin, Cout, H, W; // logical conv dims (output dims before pooling)
+  int iHp, iWp, oHp, oWp;
+  int tiles_x, tiles_y, cout_tiles, nchunks;
+};
+
+template <int KS_, int PBH_, int PBW_, int NPB_, int CC_, bool RELU_, bool POOL_>
+struct Cfg {
+  static constexpr int KS = KS_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_;
+  static constexpr bool RELU = RELU_, POOL = POOL_;
+  static constexpr int T = KS * KS;
+  static constexpr int NCB = 2, NCO = 64;
+  static constexpr int TH = 4 * NPB * PBH, TW = PBW;   // 4 waves stacked vertically
+  static constexpr int HALO = KS / 2;
+  static constexpr int LROWS = TH + 2 * HALO;
+  static constexpr int RS = (KS == 3) ? TW + 8 : TW;   // LDS row stride; 3x3 stages columns x0-4 .. x0+TW+3
+  static constexpr int XOFF = (KS == 3) ? 3 : 0;       // LDS column of pixel px under tap kx = px + kx + XOFF
+  static constexpr int IN_F4 = CC * LROWS * (RS / 4);
+  static constexpr int W_F4 = CC * T * NCO / 4;
+  static constexpr int NI = (IN_F4 + 255) / 256, NW = (W_F4 + 255) / 256;
+  static constexpr int LDS_FLOATS = CC * LROWS * RS + CC * T * NCO;
+  static_assert(PBH * PBW == 32, "a pixel block is one MFMA column block");
+  static_assert(!POOL || (PBH == 1 && NPB == 2), "fused pooling needs 2 image rows per wave");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  float* sIn = lds;
+  float* sW = lds + C::CC * C::LROWS * C::RS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
+  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int y0 = ty * C::TH, x0 = tx * C::TW;
+
+  const size_t iplane = (size_t)a.iHp * a.iWp;
+  const float* inb = a.in + (size_t)b * a.Cin * iplane;
+  // first staged element: 3x3 -> padded (row y0, col x0) == pixel (y0-1, x0-4); 1x1 -> pixel (y0, x0)
+  const int gy0 = (C::KS == 3) ? y0 : y0 + PADY;
+  const int gx0 = (C::KS == 3) ? x0 : x0 + PADX;
+  const float* wt = a.w + (size_t)ct * a.nchunks * (C::W_F4 * 4);
+
+  // per-thread staging offsets (independent of the chunk)
+  int goff[C::NI];
+#pragma unroll
+  for (int t = 0; t < C::NI; t++) {
+    const int e = tid + 256 * t;
+    const int q = e % (C::RS / 4);
+    const int r = (e / (C::RS / 4)) % C::LROWS;
+    const int c = e / ((C::RS / 4) * C::LROWS);
+    goff[t] = (e < C::IN_F4) ? (int)(c * iplane) + (gy0 + r) * a.iWp + gx0 + 4 * q : 0;  // tail lanes re-read element 0
+  }
+  int woff[C::NW];
+#pragma unroll
+  for (int t = 0; t < C::NW; t++) woff[t] = (tid + 256 * t < C::W_F4) ? tid + 256 * t : 0;
+
+  f32x16 acc[C::NCB][C::NPB];
+#pragma unroll
+  for (int cb = 0; cb < C::NCB; cb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float bv = a.bias[ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+      for (int pb = 0; pb < C::NPB; pb++) acc[cb][pb][r] = bv;
+    }
+
+  f32x4 pin[C::NI], pw[C::NW];
+  // global -> VGPR prefetch of chunk `ch` (loads are unconditional: tail lanes re-read element 0)
+#define DANI_PREFETCH(ch_)                                                                   \
+  {                                                                                          \
+    const float* src_ = inb + (size_t)(ch_) * C::CC * iplane;                                \
+    _Pragma("unroll") for (int t = 0; t < C::NI; t++)                                        \
+      pin[t] = *reinterpret_cast<const f32x4*>(src_ + goff[t]);                           \
+    const f32x4* wsrc_ = reinterpret_cast<const f32x4*>(wt + (size_t)(ch_) * (C::W_F4 * 4)); \
+    _Pragma("unroll") for (int t = 0; t < C::NW; t++)                                        \
+      pw[t] = wsrc_[woff[t]];                                                              \
+  }
+
+  const float* bA = sW + h * C::NCO + j;
+  const float* bB = sIn + (h * C::LROWS + wave * C::NPB * C::PBH + j / C::PBW) * C::RS + (j % C::PBW) + C::XOFF;
+
+  DANI_PREFETCH(0);
+  for (int ch = 0; ch < a.nchunks; ch++) {
+    __syncthreads();  // everyone finished reading the previous chunk
+#pragma unroll
+    for (int t = 0; t < C::NI; t++)
+      if (tid + 256 * t < C::IN_F4) reinterpret_cast<f32x4*>(sIn)[tid + 256 * t] = pin[t];
+#pragma unroll
+    for (int t = 0; t < C::NW; t++)
+      if (tid + 256 * t < C::W_F4) reinterpret_cast<f32x4*>(sW)[tid + 256 * t] = pw[t];
+    __syncthreads();
+    if (ch + 1 < a.nchunks) DANI_PREFETCH(ch + 1);
+
+#pragma unroll
+    for (int cp = 0; cp < C::CC / 2; cp++)
+#pragma unroll
+      for (int ky = 0; ky < C::KS; ky++)
+#pragma unroll
+        for (int kx = 0; kx < C::KS; kx++) {
+          float av[C::NCB], bv[C::NPB];
+#pragma unroll
+          for (int cb = 0; cb < C::NCB; cb++) av[cb] = bA[((cp * C::T + ky * C::KS + kx) * 2) * C::NCO + cb * 32];
+#pragma unroll
+          for (int pb = 0; pb < C::NPB; pb++) bv[pb] = bB[(2 * cp * C::LROWS + pb * C::PBH + ky) * C::RS + kx];
+#pragma unroll
+          for (int cb = 0; cb < C::NCB; cb++)
+#pragma unroll
+            for (int pb = 0; pb < C::NPB; pb++)
+              acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[pb], acc[cb][pb], 0, 0, 0);
+        }
+  }
+
+#undef DANI_PREFETCH
+  // ---- epilogue ----
+  const size_t oplane = (size_t)a.oHp * a.oWp;
+  float* outb = a.out + (size_t)b * a.Cout * oplane;
+  if constexpr (C::POOL) {
+    const int yo = (y0 + wave * 2) >> 1, xo = (x0 + j) >> 1;
+    const bool ok = ((j & 1) == 0) && yo < (a.H >> 1) && xo < (a.W >> 1);
+#pragma unroll
+    for (int cb = 0; cb < C::NCB; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float m = fmaxf(acc[cb][0][r], acc[cb][1][r]);
+        m = fmaxf(m, __shfl_xor(m, 1));
+        if (C::RELU) m = m > 0.0f ? m : 0.0f;
+        const int co = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (ok && co < a.Cout) outb[(size_t)co * oplane + (size_t)(yo + PADY) * a.oWp + xo + PADX] = m;
+      }
+  } else {
+#pragma unroll
+    for (int pb = 0; pb < C::NPB; pb++) {
+      const int y = y0 + wave * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
+      const bool ok = y < a.H && x < a.W;
+#pragma unroll
+      for (int cb = 0; cb < C::NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          float v = acc[cb][pb][r];
+          if (C::RELU) v = v > 0.0f ? v : 0.0f;
+          const int co = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (ok && co < a.Cout) outb[(size_t)co * oplane + (size_t)(y + PADY) * a.oWp + x + PADX] = v;
+        }
+    }
+  }
+}
+
+using CfgRow32Relu = Cfg<3, 1, 32, 2, 8, true, false>;
+using CfgRow32ReluPool = Cfg<3, 1, 32, 2, 8, true, true>;
+using CfgBlk16Relu = Cfg<3, 2, 16, 2, 8, true, false>;
+using CfgConv1Blk16 = Cfg<1, 2, 16, 2, 32, false, false>;
+
+template <class C>
+static void launch_cfg(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s) {
+  ConvArgs a;
+  a.in = in.p; a.w = L.w_packed; a.bias = L.bias_packed; a.out = out.p;
+  a.Cin = L.Cin; a.Cout = L.Cout; a.H = in.H; a.W = in.W;
+  a.iHp = in.Hp; a.iWp = in.Wp; a.oHp = out.Hp; a.oWp = out.Wp;
+  a.tiles_x = (in.W + C::TW - 1) / C::TW;
+  a.tiles_y = (in.H + C::TH - 1) / C::TH;
+  a.cout_tiles = L.cout_tiles;
+  a.nchunks = L.Cin / C::CC;
+  const int grid = B * a.tiles_x * a.tiles_y * a.cout_tiles;
+  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), 0, s, a);
+}
+
+void launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s) {
+  switch (L.variant) {
+    case CONV3_ROW32_RELU: launch_cfg<CfgRow32Relu>(L, in, out, B, s); break;
+    case CONV3_ROW32_RELU_POOL: launch_cfg<CfgRow32ReluPool>(L, in, out, B, s); break;
+    case CONV3_BLK16_RELU: launch_cfg<CfgBlk16Relu>(L, in, out, B, s); break;
+    case CONV1_BLK16_LINEAR: launch_cfg<CfgConv1Blk16>(L, in, out, B, s); break;
+  }
+}
+
+const char* conv_kernel_name(ConvVariant v) {
+  switch (v) {
+    case CONV3_ROW32_RELU: return "conv_mfma_kernel<Cfg<3,1,32,2,8,true,false>>";
+    case CONV3_ROW32_RELU_POOL: return "conv_mfma_kernel<Cfg<3,1,32,2,8,true,true>>";
+    case CONV3_BLK16_RELU: return "conv_mfma_kernel<Cfg<3,2,16,2,8,true,false>>";
+    case CONV1_BLK16_LINEAR: return "conv_mfma_kernel<Cfg<1,2,16,2,32,false,false>>";
+  }
+  return "?";
+}
+
+// OIHW -> [cout_tile][chunk][cp][tap][cc][NCO]; couts beyond Cout are zero rows.
+void pack_conv_weights(const float* w, const float* bias, int Cin, int Cout, int ks, int CC, int NCO, float* wp,
+                       float* bp) {
+  const int T = ks * ks, cout_tiles = (Cout + NCO - 1) / NCO, nch = Cin / CC;
+  size_t o = 0;
+  for (int ct = 0; ct < cout_tiles; ct++)
+    for (int ch = 0; ch < nch; ch++)
+      for (int cp = 0; cp < CC / 2; cp++)
+        for (int t = 0; t < T; t++)
+          for (int cc = 0; cc < 2; cc++)
+            for (int co = 0; co < NCO; co++) {
+              const int cout = ct * NCO + co, cin = ch * CC + 2 * cp + cc;
+              wp[o++] = (cout < Cout) ? w[((size_t)cout * Cin + cin) * T + t] : 0.0f;
+            }
+  for (int i = 0; i < cout_tiles * NCO; i++) bp[i] = (i < Cout) ? bias[i] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv1a: Cin = 1, K = 9 -- not MFMA-shaped (0.35 GFLOP, HBM-bound on its 78.6 MB output at 640x480).
+// Fuses SPDetector::detect's u8 -> f32 / 255 (/root/reference/src/SuperPoint.cpp:192-193) with
+// relu(conv1a(x)) (:58).  One thread per pixel, 64 couts in a loop, weights through the scalar cache.
+// Canonical order for Cin = 1: acc = bias; taps in (ky, kx) order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* img, int H, int W, int stride, size_t fstride,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     float* out, int oHp, int oWp) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.z;
+  if (x >= W || y >= H) return;
+  const uint8_t* im = img + (size_t)b * fstride;
+  float p[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+      const int yy = y + ky - 1, xx = x + kx - 1;
+      p[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)im[(size_t)yy * stride + xx] / 255.0f : 0.0f;
+    }
+  const size_t oplane = (size_t)oHp * oWp;
+  float* o = out + (size_t)b * 64 * oplane + (size_t)(y + PADY) * oWp + x + PADX;
+#pragma unroll 4
+  for (int co = 0; co < 64; co++) {
+    float acc = bias[co];
+#pragma unroll
+    for (int t = 0; t < 9; t++) acc = __builtin_fmaf(p[t], w[co * 9 + t], acc);
+    o[(size_t)co * oplane] = acc > 0.0f ? acc : 0.0f;
+  }
+}
+
+void launch_conv1a(const uint8_t* img, int B, int H, int W, int stride, size_t fstride, const float* w,
+                   const float* bias, const ActDesc& out, hipStream_t s) {
+  dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+  hipLaunchKernelGGL(conv1a_kernel, grid, dim3(256), 0, s, img, H, W, stride, fstride, w, bias, out.p, out.Hp, out.Wp);
+}
+
+}  // namespace dani

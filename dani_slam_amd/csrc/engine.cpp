@@ -1,0 +1,553 @@
+// engine.cpp -- implementation of the C ABI in include/dani_frontend.h (SuperPoint part).
+//
+// Host side of the reference calls replaced here:
+//   SPextractor::SPextractor / operator() / ComputeKeyPointsOctTree   /root/reference/src/SPextractor.cpp:80-386
+//   SPDetector::detect / getKeyPoints / computeDescriptors             src/SuperPoint.cpp:186-274
+// There is no CPU compute path in this file: every stage of the network runs in the HIP kernels of
+// conv_mfma.hip / sp_post.hip; only the order-defining quadtree (host_logic.cpp) runs on the host, as it does
+// in the reference.
+#include "../../include/dani_frontend.h"
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace dani;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct SpLayerDef { const char* name; int cin, cout, k; };
+const SpLayerDef kSp[12] = {
+    {"conv1a", 1, 64, 3},    {"conv1b", 64, 64, 3},   {"conv2a", 64, 64, 3},    {"conv2b", 64, 64, 3},
+    {"conv3a", 64, 128, 3},  {"conv3b", 128, 128, 3}, {"conv4a", 128, 128, 3},  {"conv4b", 128, 128, 3},
+    {"convPa", 128, 256, 3}, {"convPb", 256, 65, 1},  {"convDa", 128, 256, 3},  {"convDb", 256, 256, 1}};
+const ConvVariant kSpVariant[12] = {
+    CONV3_ROW32_RELU /*unused for 1a*/, CONV3_ROW32_RELU_POOL, CONV3_ROW32_RELU, CONV3_ROW32_RELU_POOL,
+    CONV3_ROW32_RELU, CONV3_ROW32_RELU_POOL, CONV3_BLK16_RELU, CONV3_BLK16_RELU,
+    CONV3_BLK16_RELU, CONV1_BLK16_LINEAR, CONV3_BLK16_RELU, CONV1_BLK16_LINEAR};
+
+constexpr int CAND_CAP = 32768;  // candidates per frame kept on the device (reference reserves 10*nfeatures)
+
+struct Context {
+  hipStream_t stream = nullptr;
+  int W = 0, H = 0, B = 0;  // shapes the buffers are built for
+  ActDesc act[12];          // output of layer i (layers 1,3,5: pooled)
+  float* prob = nullptr;
+  float* desc_nhwc = nullptr;
+  float* desc_nchw = nullptr;
+  std::vector<CellRect> cells;
+  CellRect* d_cells = nullptr;
+  int slot_stride = 0;
+  float* slot_xyr = nullptr;
+  int32_t* slot_count = nullptr;
+  float* cand = nullptr;
+  int32_t* cand_count = nullptr;
+  int32_t* d_boxes = nullptr;
+  int32_t* d_box_offsets = nullptr;
+  int box_cap = 0;
+  uint8_t* d_img = nullptr;
+  size_t d_img_bytes = 0;
+  float* d_kxy = nullptr;
+  int32_t* d_nk = nullptr;
+  float* d_sampled = nullptr;
+  float* d_descout = nullptr;
+  int kcap = 0;
+  // pinned host staging
+  float* h_cand = nullptr;
+  int32_t* h_cand_count = nullptr;
+  float* h_kxy = nullptr;  // [B][kcap][2] followed by nk[B]
+  int32_t* h_boxes = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t lev[13] = {};
+  float ms[5] = {0, 0, 0, 0, 0};
+  float layer_ms[12] = {};
+  std::vector<void*> dev_allocs, host_allocs;
+  bool busy = false;
+};
+
+}  // namespace
+
+struct dani_engine {
+  dani_config cfg;
+  int device = 0;
+  std::string err;
+  std::map<std::string, std::vector<float>> tensors;
+  bool finalized = false;
+  ConvLayerPlan plan[12];
+  float* w1a = nullptr;
+  float* b1a = nullptr;
+  std::vector<void*> weight_allocs;
+  std::vector<Context*> ctxs;
+  std::mutex mu;
+  bool profiling = false;
+};
+
+namespace {
+
+int fail(dani_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                            \
+  do {                                                                                              \
+    hipError_t _st = (call);                                                                        \
+    if (_st != hipSuccess)                                                                          \
+      return fail((e), DANI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_st), __FILE__, __LINE__); \
+  } while (0)
+
+thread_local Context* t_last_ctx = nullptr;
+
+Context* acquire(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (Context* c : e->ctxs)
+    if (!c->busy) { c->busy = true; return c; }
+  return nullptr;
+}
+void release(dani_engine* e, Context* c) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  c->busy = false;
+}
+
+int dev_alloc(dani_engine* e, Context* c, void** p, size_t bytes, bool zero) {
+  HIP_TRY(e, hipMalloc(p, bytes));
+  c->dev_allocs.push_back(*p);
+  if (zero) HIP_TRY(e, hipMemsetAsync(*p, 0, bytes, c->stream));
+  return 0;
+}
+int host_alloc(dani_engine* e, Context* c, void** p, size_t bytes) {
+  HIP_TRY(e, hipHostMalloc(p, bytes, hipHostMallocDefault));
+  c->host_allocs.push_back(*p);
+  return 0;
+}
+
+void free_buffers(Context* c) {
+  for (void* p : c->dev_allocs) (void)hipFree(p);
+  for (void* p : c->host_allocs) (void)hipHostFree(p);
+  c->dev_allocs.clear();
+  c->host_allocs.clear();
+  c->W = c->H = c->B = 0;
+}
+
+// (re)build the per-context buffers for image size W x H and batch B
+int ensure_shapes(dani_engine* e, Context* c, int W, int H, int B, int kcap) {
+  if (c->W == W && c->H == H && c->B >= B && c->kcap >= kcap) return 0;
+  HIP_TRY(e, hipStreamSynchronize(c->stream));
+  free_buffers(c);
+  const int dims[12][2] = {{H, W}, {H / 2, W / 2}, {H / 2, W / 2}, {H / 4, W / 4}, {H / 4, W / 4}, {H / 8, W / 8},
+                           {H / 8, W / 8}, {H / 8, W / 8}, {H / 8, W / 8}, {H / 8, W / 8}, {H / 8, W / 8}, {H / 8, W / 8}};
+  for (int i = 0; i < 12; i++) {
+    act_shape(c->act[i], kSp[i].cout, dims[i][0], dims[i][1]);
+    int rc = dev_alloc(e, c, (void**)&c->act[i].p, c->act[i].bytes(B), true);  // zero borders, once
+    if (rc) return rc;
+  }
+  const int Hc = H / 8, Wc = W / 8, PH = Hc * 8, PW = Wc * 8;
+  int rc;
+  if ((rc = dev_alloc(e, c, (void**)&c->prob, (size_t)B * PH * PW * 4, false))) return rc;
+  if ((rc = dev_alloc(e, c, (void**)&c->desc_nhwc, (size_t)B * Hc * Wc * 256 * 4, false))) return rc;
+  if ((rc = dev_alloc(e, c, (void**)&c->desc_nchw, (size_t)B * Hc * Wc * 256 * 4, false))) return rc;
+  cell_grid(W, H, c->cells);
+  int max_area = 1;
+  for (const CellRect& r : c->cells) {
+    const int w = r.maxX - r.iniX, h = r.maxY - r.iniY;
+    if (w > CELL_MAX_DIM || h > CELL_MAX_DIM || w <= 0 || h <= 0)
+      return fail(e, DANI_ERR_UNSUPPORTED, "cell %dx%d exceeds the %d-pixel cell kernel limit", w, h, CELL_MAX_DIM);
+    max_area = std::max(max_area, w * h);
+  }
+  c->slot_stride = max_area;
+  const int nc = std::max<int>(1, (int)c->cells.size());
+  if ((rc = dev_alloc(e, c, (void**)&c->d_cells, sizeof(CellRect) * nc, false))) return rc;
+  if (!c->cells.empty())
+    HIP_TRY(e, hipMemcpyAsync(c->d_cells, c->cells.data(), sizeof(CellRect) * c->cells.size(), hipMemcpyHostToDevice, c->stream));
+  if ((rc = dev_alloc(e, c, (void**)&c->slot_xyr, (size_t)B * nc * c->slot_stride * 3 * 4, false))) return rc;
+  if ((rc = dev_alloc(e, c, (void**)&c->slot_count, (size_t)B * nc * 4, true))) return rc;
+  if ((rc = dev_alloc(e, c, (void**)&c->cand, (size_t)B * CAND_CAP * 3 * 4, false))) return rc;
+  if ((rc = dev_alloc(e, c, (void**)&c->cand_count, (size_t)B * 4, true))) return rc;
+  c->box_cap = 1024;
+  if ((rc = dev_alloc(e, c, (void**)&c->d_boxes, (size_t)(c->box_cap * 4 + B + 1) * 4, true))) return rc;
+  c->d_box_offsets = c->d_boxes + c->box_cap * 4;
+  c->d_img_bytes = (size_t)B * H * round_up(W, 64) * 2;
+  if ((rc = dev_alloc(e, c, (void**)&c->d_img, c->d_img_bytes, false))) return rc;
+  c->kcap = kcap;
+  if ((rc = dev_alloc(e, c, (void**)&c->d_kxy, ((size_t)B * kcap * 2 + B) * 4, false))) return rc;
+  c->d_nk = reinterpret_cast<int32_t*>(c->d_kxy + (size_t)B * kcap * 2);
+  if ((rc = dev_alloc(e, c, (void**)&c->d_sampled, ((size_t)B * kcap * 256 + B * 256) * 4, false))) return rc;
+  if ((rc = dev_alloc(e, c, (void**)&c->d_descout, (size_t)B * kcap * 256 * 4, false))) return rc;
+  if ((rc = host_alloc(e, c, (void**)&c->h_cand, (size_t)B * CAND_CAP * 3 * 4))) return rc;
+  if ((rc = host_alloc(e, c, (void**)&c->h_cand_count, (size_t)B * 4))) return rc;
+  if ((rc = host_alloc(e, c, (void**)&c->h_kxy, ((size_t)B * kcap * 2 + B) * 4))) return rc;
+  if ((rc = host_alloc(e, c, (void**)&c->h_boxes, (size_t)(c->box_cap * 4 + B + 1) * 4))) return rc;
+  HIP_TRY(e, hipStreamSynchronize(c->stream));
+  c->W = W; c->H = H; c->B = B;
+  return 0;
+}
+
+int check_params(dani_engine* e, int W, int H, const dani_sp_params* p) {
+  if (!p) return fail(e, DANI_ERR_INVALID, "null params");
+  if (p->nlevels != 1)
+    return fail(e, DANI_ERR_UNSUPPORTED, "nlevels=%d: only nlevels=1 is implemented (the reference's tuned YAMLs, "
+                "Examples/RGB-D/TUM3.yaml:42-55, use 1)", p->nlevels);
+  if (W % 8 || H % 8 || W < 80 || H < 80)
+    return fail(e, DANI_ERR_UNSUPPORTED, "image %dx%d: width and height must be multiples of 8 and >= 80", W, H);
+  if (W > e->cfg.max_width || H > e->cfg.max_height)
+    return fail(e, DANI_ERR_INVALID, "image %dx%d exceeds the engine's configured maximum %dx%d", W, H, e->cfg.max_width, e->cfg.max_height);
+  if (p->nfeatures <= 0 || !(p->ini_th >= 0.0f) || !(p->min_th >= 0.0f)) return fail(e, DANI_ERR_INVALID, "bad extractor params");
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* dani_version(void) { return "dani-frontend-hip 0.1 (gfx950)"; }
+
+const char* dani_last_error(const dani_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int dani_engine_create(const dani_config* cfg, dani_engine** out) {
+  if (!cfg || !out) return fail(nullptr, DANI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, DANI_ERR_NO_DEVICE, "no HIP device visible; this engine has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, DANI_ERR_NO_DEVICE, "device %d out of range (%d devices)", cfg->device, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(nullptr, DANI_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, DANI_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+  dani_engine* e = new dani_engine();
+  e->cfg = *cfg;
+  if (e->cfg.max_batch < 1) e->cfg.max_batch = 1;
+  if (e->cfg.n_contexts < 1) e->cfg.n_contexts = 2;
+  if (e->cfg.max_width < 80) e->cfg.max_width = 640;
+  if (e->cfg.max_height < 80) e->cfg.max_height = 480;
+  e->device = cfg->device;
+  if (hipSetDevice(e->device) != hipSuccess) { delete e; return fail(nullptr, DANI_ERR_HIP, "hipSetDevice failed"); }
+  for (int i = 0; i < e->cfg.n_contexts; i++) {
+    Context* c = new Context();
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    for (auto& ev : c->lev) (void)hipEventCreate(&ev);
+    e->ctxs.push_back(c);
+  }
+  *out = e;
+  return DANI_OK;
+}
+
+void dani_engine_destroy(dani_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (Context* c : e->ctxs) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_buffers(c);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->lev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+  }
+  for (void* p : e->weight_allocs) (void)hipFree(p);
+  delete e;
+}
+
+int dani_set_tensor(dani_engine* e, const char* name, const float* data, int64_t count) {
+  if (!e || !name || !data || count <= 0) return fail(e, DANI_ERR_INVALID, "bad dani_set_tensor argument");
+  e->tensors[name].assign(data, data + count);
+  e->finalized = false;
+  return DANI_OK;
+}
+
+int dani_load_weights_file(dani_engine* e, const char* path) {
+  // .dsw container: "DSW1", u32 n, then n x { u32 name_len, name, u64 count, count x f32 }
+  if (!e || !path) return fail(e, DANI_ERR_INVALID, "null argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(e, DANI_ERR_WEIGHTS, "cannot open weight file %s", path);
+  char magic[4];
+  uint32_t n = 0;
+  bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "DSW1", 4) == 0 && fread(&n, 4, 1, f) == 1;
+  for (uint32_t i = 0; ok && i < n; i++) {
+    uint32_t nl = 0;
+    uint64_t cnt = 0;
+    ok = fread(&nl, 4, 1, f) == 1 && nl < 256;
+    std::string name(nl, '\0');
+    ok = ok && fread(&name[0], 1, nl, f) == nl && fread(&cnt, 8, 1, f) == 1 && cnt < (1ull << 28);
+    if (!ok) break;
+    std::vector<float> v(cnt);
+    ok = fread(v.data(), 4, cnt, f) == cnt;
+    if (ok) e->tensors[name].swap(v);
+  }
+  fclose(f);
+  if (!ok) return fail(e, DANI_ERR_WEIGHTS, "malformed weight file %s", path);
+  e->finalized = false;
+  return DANI_OK;
+}
+
+int dani_finalize_weights(dani_engine* e) {
+  if (!e) return DANI_ERR_INVALID;
+  HIP_TRY(e, hipSetDevice(e->device));
+  for (void* p : e->weight_allocs) (void)hipFree(p);
+  e->weight_allocs.clear();
+  for (int i = 0; i < 12; i++) {
+    const SpLayerDef& d = kSp[i];
+    const std::string wn = std::string(d.name) + ".weight", bn = std::string(d.name) + ".bias";
+    auto wi = e->tensors.find(wn), bi = e->tensors.find(bn);
+    if (wi == e->tensors.end() || bi == e->tensors.end())
+      return fail(e, DANI_ERR_WEIGHTS, "missing tensor %s / %s", wn.c_str(), bn.c_str());
+    const size_t wexp = (size_t)d.cout * d.cin * d.k * d.k;
+    if (wi->second.size() != wexp || bi->second.size() != (size_t)d.cout)
+      return fail(e, DANI_ERR_WEIGHTS, "tensor %s has %zu floats, expected %zu ([%d,%d,%d,%d])", wn.c_str(), wi->second.size(), wexp, d.cout, d.cin, d.k, d.k);
+    if (i == 0) {
+      HIP_TRY(e, hipMalloc((void**)&e->w1a, wexp * 4)); e->weight_allocs.push_back(e->w1a);
+      HIP_TRY(e, hipMalloc((void**)&e->b1a, d.cout * 4)); e->weight_allocs.push_back(e->b1a);
+      HIP_TRY(e, hipMemcpy(e->w1a, wi->second.data(), wexp * 4, hipMemcpyHostToDevice));
+      HIP_TRY(e, hipMemcpy(e->b1a, bi->second.data(), d.cout * 4, hipMemcpyHostToDevice));
+      continue;
+    }
+    ConvLayerPlan& L = e->plan[i];
+    L.variant = kSpVariant[i];
+    L.Cin = d.cin; L.Cout = d.cout; L.ksize = d.k;
+    L.CC = conv_variant_cc(L.variant);
+    L.cout_tiles = (d.cout + 63) / 64;
+    L.w_packed_floats = (size_t)L.cout_tiles * 64 * d.cin * d.k * d.k;
+    std::vector<float> wp(L.w_packed_floats), bp((size_t)L.cout_tiles * 64);
+    pack_conv_weights(wi->second.data(), bi->second.data(), d.cin, d.cout, d.k, L.CC, 64, wp.data(), bp.data());
+    HIP_TRY(e, hipMalloc((void**)&L.w_packed, wp.size() * 4)); e->weight_allocs.push_back(L.w_packed);
+    HIP_TRY(e, hipMalloc((void**)&L.bias_packed, bp.size() * 4)); e->weight_allocs.push_back(L.bias_packed);
+    HIP_TRY(e, hipMemcpy(L.w_packed, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(L.bias_packed, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  }
+  e->finalized = true;
+  return DANI_OK;
+}
+
+int dani_set_profiling(dani_engine* e, int on) {
+  if (!e) return DANI_ERR_INVALID;
+  e->profiling = on != 0;
+  return DANI_OK;
+}
+
+int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_device, int32_t B, int32_t W, int32_t H,
+                          int32_t stride, const dani_sp_params* p, const int32_t* boxes, const int32_t* box_offsets,
+                          const int32_t lapping[2], float* kpts_xy, float* resp, int32_t* octave, float* size,
+                          float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!imgs || W <= 0 || H <= 0) return fail(e, DANI_ERR_EMPTY, "empty image");
+  if (!e->finalized) return fail(e, DANI_ERR_WEIGHTS, "weights not finalized (call dani_finalize_weights)");
+  if (B < 1 || B > e->cfg.max_batch) return fail(e, DANI_ERR_INVALID, "batch %d outside [1, %d]", B, e->cfg.max_batch);
+  if (stride < W || cap < 1 || !n_out || !kpts_xy || !resp || !desc) return fail(e, DANI_ERR_INVALID, "bad argument");
+  int rc = check_params(e, W, H, p);
+  if (rc) return rc;
+  HIP_TRY(e, hipSetDevice(e->device));
+  Context* c = acquire(e);
+  if (!c) return fail(e, DANI_ERR_INVALID, "all %d contexts busy (raise dani_config.n_contexts)", e->cfg.n_contexts);
+  struct Releaser { dani_engine* e; Context* c; ~Releaser() { release(e, c); } } rel{e, c};
+  t_last_ctx = c;
+  std::vector<int> per_level; std::vector<float> scales;
+  features_per_level(p->nfeatures, p->scale_factor, p->nlevels, per_level, scales);
+  const int N = per_level[0];
+  const int kcap = N + 8;  // DistributeOctTree can exceed N by at most 3
+  if ((rc = ensure_shapes(e, c, W, H, e->cfg.max_batch, std::max(kcap, c->kcap)))) return rc;
+  hipStream_t s = c->stream;
+  const int Hc = H / 8, Wc = W / 8, PH = Hc * 8, PW = Wc * 8;
+  const int ncells = (int)c->cells.size();
+
+  // ---- inputs
+  const uint8_t* dimg = imgs;
+  const size_t fbytes = (size_t)H * stride;
+  if (!imgs_on_device) {
+    if (fbytes * B > c->d_img_bytes) return fail(e, DANI_ERR_INVALID, "stride %d too large for the staging buffer", stride);
+    HIP_TRY(e, hipMemcpyAsync(c->d_img, imgs, fbytes * B, hipMemcpyHostToDevice, s));
+    dimg = c->d_img;
+  }
+  int nboxes_total = 0;
+  if (boxes && box_offsets) nboxes_total = box_offsets[B];
+  if (nboxes_total > c->box_cap) return fail(e, DANI_ERR_INVALID, "too many dynamic boxes (%d)", nboxes_total);
+  {
+    int32_t* hb = c->h_boxes;
+    if (nboxes_total) memcpy(hb, boxes, (size_t)nboxes_total * 16);
+    int32_t* ho = hb + c->box_cap * 4;
+    for (int b = 0; b <= B; b++) ho[b] = (boxes && box_offsets) ? box_offsets[b] : 0;
+    if (nboxes_total) HIP_TRY(e, hipMemcpyAsync(c->d_boxes, hb, (size_t)nboxes_total * 16, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(c->d_box_offsets, ho, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
+  }
+
+  // ---- network
+  const bool prof = e->profiling;
+  HIP_TRY(e, hipEventRecord(c->ev[0], s));
+  if (prof) HIP_TRY(e, hipEventRecord(c->lev[0], s));
+  launch_conv1a(dimg, B, H, W, stride, fbytes, e->w1a, e->b1a, c->act[0], s);
+  if (prof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
+  const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
+  for (int i = 1; i < 12; i++) {
+    launch_conv_mfma(e->plan[i], c->act[src_of[i]], c->act[i], B, s);
+    if (prof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
+  }
+  HIP_TRY(e, hipEventRecord(c->ev[1], s));
+  launch_softmax_d2s(c->act[9], c->prob, B, s);
+  launch_desc_norm(c->act[11], c->desc_nhwc, c->desc_nchw, B, s);
+  if (ncells > 0) {
+    launch_cell_nms(c->prob, PH, PW, B, c->d_cells, ncells, p->ini_th, p->min_th, c->d_boxes, c->d_box_offsets,
+                    19 - 3, c->slot_xyr, c->slot_count, c->slot_stride, s);
+    launch_cell_compact(c->slot_xyr, c->slot_count, ncells, c->slot_stride, B, c->cand, c->cand_count, CAND_CAP, s);
+  }
+  HIP_TRY(e, hipEventRecord(c->ev[2], s));
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(c->h_cand_count, c->cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  for (int b = 0; b < B; b++) {
+    int nc = ncells > 0 ? c->h_cand_count[b] : 0;
+    if (nc > CAND_CAP) return fail(e, DANI_ERR_CAPACITY, "frame %d has %d candidates (> %d)", b, nc, CAND_CAP);
+    c->h_cand_count[b] = nc;
+    if (nc) HIP_TRY(e, hipMemcpyAsync(c->h_cand + (size_t)b * CAND_CAP * 3, c->cand + (size_t)b * CAND_CAP * 3, (size_t)nc * 12, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(e, hipStreamSynchronize(s));
+
+  // ---- host: quadtree, keypoint assembly (SPextractor.cpp:359-376, :164-216)
+  const auto t0 = std::chrono::steady_clock::now();
+  const int minBorderX = 19 - 3, minBorderY = minBorderX, maxBorderX = W - 19 + 3, maxBorderY = H - 19 + 3;
+  const int scaledPatchSize = (int)(31 * scales[0]);
+  int32_t* h_nk = reinterpret_cast<int32_t*>(c->h_kxy + (size_t)e->cfg.max_batch * c->kcap * 2);
+  std::vector<int> sel;
+  int status = DANI_OK;
+  for (int b = 0; b < B; b++) {
+    const HostKey* keys = reinterpret_cast<const HostKey*>(c->h_cand + (size_t)b * CAND_CAP * 3);
+    const int nc = c->h_cand_count[b];
+    distribute_octtree(keys, nc, minBorderX, maxBorderX, minBorderY, maxBorderY, N, sel);
+    const int n = (int)sel.size();
+    n_out[b] = n;
+    if (n > cap || n > c->kcap) { status = DANI_ERR_CAPACITY; h_nk[b] = 0; continue; }
+    h_nk[b] = n;
+    float* kx = c->h_kxy + (size_t)b * c->kcap * 2;
+    for (int i = 0; i < n; i++) { kx[2 * i] = keys[sel[i]].x + minBorderX; kx[2 * i + 1] = keys[sel[i]].y + minBorderY; }
+    // mono / stereo partition of the keypoints only (descriptor rows keep the pre-partition order)
+    int monoIndex = 0, stereoIndex = n - 1;
+    float* ok = kpts_xy + (size_t)b * cap * 2;
+    float* orr = resp + (size_t)b * cap;
+    const int l0 = lapping ? lapping[0] : 0, l1 = lapping ? lapping[1] : 0;
+    for (int i = 0; i < n; i++) {
+      const float x = kx[2 * i], y = kx[2 * i + 1];
+      const int dst = (x >= (float)l0 && x <= (float)l1) ? stereoIndex-- : monoIndex++;
+      ok[2 * dst] = x; ok[2 * dst + 1] = y; orr[dst] = keys[sel[i]].r;
+    }
+    if (octave) for (int i = 0; i < n; i++) octave[(size_t)b * cap + i] = 0;
+    if (size) for (int i = 0; i < n; i++) size[(size_t)b * cap + i] = (float)scaledPatchSize;
+    if (mono_index) mono_index[b] = monoIndex;
+  }
+  c->ms[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (status != DANI_OK) return fail(e, status, "output capacity %d too small", cap);
+
+  // ---- descriptors
+  HIP_TRY(e, hipMemcpyAsync(c->d_kxy, c->h_kxy, ((size_t)e->cfg.max_batch * c->kcap * 2 + B) * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(e, hipEventRecord(c->ev[3], s));
+  launch_descriptors(c->desc_nhwc, Hc, Wc, PH, PW, c->d_kxy, c->d_nk, B, c->kcap, c->d_sampled, c->d_descout, s);
+  HIP_TRY(e, hipEventRecord(c->ev[4], s));
+  for (int b = 0; b < B; b++)
+    if (n_out[b])
+      HIP_TRY(e, hipMemcpyAsync(desc + (size_t)b * cap * 256, c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  HIP_TRY(e, hipGetLastError());
+  (void)hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&c->ms[3], c->ev[3], c->ev[4]);
+  (void)hipEventElapsedTime(&c->ms[4], c->ev[0], c->ev[4]);
+  if (prof)
+    for (int i = 0; i < 12; i++) (void)hipEventElapsedTime(&c->layer_ms[i], c->lev[i], c->lev[i + 1]);
+  return DANI_OK;
+}
+
+int dani_sp_extract(dani_engine* e, const uint8_t* img, int32_t W, int32_t H, int32_t stride, const dani_sp_params* p,
+                    const int32_t* boxes, int32_t nboxes, const int32_t lapping[2], float* kpts_xy, float* resp,
+                    int32_t* octave, float* size, float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index) {
+  const int32_t offs[2] = {0, nboxes};
+  return dani_sp_extract_batch(e, img, 0, 1, W, H, stride, p, boxes, (boxes && nboxes > 0) ? offs : nullptr, lapping,
+                               kpts_xy, resp, octave, size, desc, cap, n_out, mono_index);
+}
+
+int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* desc_map, float* cand_xyr, int32_t cand_cap,
+                        int32_t* n_cand) {
+  Context* c = t_last_ctx;
+  if (!e || !c || b < 0 || b >= c->B) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
+  HIP_TRY(e, hipSetDevice(e->device));
+  const int Hc = c->H / 8, Wc = c->W / 8;
+  if (prob) HIP_TRY(e, hipMemcpy(prob, c->prob + (size_t)b * Hc * 8 * Wc * 8, (size_t)Hc * 8 * Wc * 8 * 4, hipMemcpyDeviceToHost));
+  if (desc_map) HIP_TRY(e, hipMemcpy(desc_map, c->desc_nchw + (size_t)b * 256 * Hc * Wc, (size_t)256 * Hc * Wc * 4, hipMemcpyDeviceToHost));
+  if (n_cand) *n_cand = c->h_cand_count[b];
+  if (cand_xyr) {
+    const int n = std::min(c->h_cand_count[b], cand_cap);
+    memcpy(cand_xyr, c->h_cand + (size_t)b * CAND_CAP * 3, (size_t)n * 12);
+  }
+  return DANI_OK;
+}
+
+int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, int64_t count) {
+  Context* c = t_last_ctx;
+  if (!e || !c || b < 0 || b >= c->B || layer < 0 || layer >= 12 || !out) return fail(e, DANI_ERR_INVALID, "bad argument");
+  const ActDesc& a = c->act[layer];
+  const size_t need = (size_t)a.C * a.H * a.W;
+  if ((size_t)count < need) return fail(e, DANI_ERR_CAPACITY, "layer %d needs %zu floats", layer, need);
+  HIP_TRY(e, hipSetDevice(e->device));
+  float* tmp = nullptr;
+  HIP_TRY(e, hipMalloc((void**)&tmp, need * 4));
+  launch_copy_layer_dense(a, b, tmp, c->stream);
+  hipError_t st = hipMemcpyAsync(out, tmp, need * 4, hipMemcpyDeviceToHost, c->stream);
+  if (st == hipSuccess) st = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  if (st != hipSuccess) return fail(e, DANI_ERR_HIP, "debug layer copy failed: %s", hipGetErrorString(st));
+  return DANI_OK;
+}
+
+int dani_last_timings(dani_engine* e, float* ms, int32_t n) {
+  Context* c = t_last_ctx;
+  if (!e || !c || !ms) return DANI_ERR_INVALID;
+  for (int i = 0; i < n && i < 5; i++) ms[i] = c->ms[i];
+  return DANI_OK;
+}
+
+int dani_layer_timings(dani_engine* e, float* ms12) {
+  Context* c = t_last_ctx;
+  if (!e || !c || !ms12) return DANI_ERR_INVALID;
+  for (int i = 0; i < 12; i++) ms12[i] = c->layer_ms[i];
+  return DANI_OK;
+}
+
+// ---- host logic, callable without a GPU ----------------------------------------------------------
+int dani_host_distribute_octtree(const float* in_xyr, int32_t n, int32_t min_x, int32_t max_x, int32_t min_y,
+                                 int32_t max_y, int32_t n_features, int32_t* out_idx, int32_t cap) {
+  if (n < 0 || (n && !in_xyr) || !out_idx) return DANI_ERR_INVALID;
+  std::vector<int> sel;
+  distribute_octtree(reinterpret_cast<const HostKey*>(in_xyr), n, min_x, max_x, min_y, max_y, n_features, sel);
+  if ((int)sel.size() > cap) return DANI_ERR_CAPACITY;
+  for (size_t i = 0; i < sel.size(); i++) out_idx[i] = sel[i];
+  return (int)sel.size();
+}
+
+int dani_host_cell_grid(int32_t width, int32_t height, int32_t* cells6, int32_t cap) {
+  std::vector<CellRect> cells;
+  const int n = cell_grid(width, height, cells);
+  for (int i = 0; i < n && i < cap; i++) memcpy(cells6 + 6 * i, &cells[i], 24);
+  return n;
+}
+
+int dani_host_features_per_level(int32_t nfeatures, float scale_factor, int32_t nlevels, int32_t* per_level,
+                                 float* scale_factors) {
+  if (nlevels < 1 || !per_level) return DANI_ERR_INVALID;
+  std::vector<int> f; std::vector<float> s;
+  features_per_level(nfeatures, scale_factor, nlevels, f, s);
+  for (int i = 0; i < nlevels; i++) { per_level[i] = f[i]; if (scale_factors) scale_factors[i] = s[i]; }
+  return DANI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+// host_logic.cpp -- the order-sensitive host stages of the extractor, implemented for speed with flat
+// arrays (the reference uses std::list<ExtractorNode> holding std::vector<cv::KeyPoint> copies):
+//   cell grid of ComputeKeyPointsOctTree      /root/reference/src/SPextractor.cpp:232-266
+//   DistributeOctTree / DivideNode            src/SPextractor.cpp:21-77, 388-629
+//   mnFeaturesPerLevel / scale tables         src/SPextractor.cpp:97-126
+// The quadtree output ORDER is part of the contract (it is the keypoint order seen by Frame), so the
+// list discipline of the reference (push_front of children n1..n4, erase of the parent, largest-first
+// expansion after std::sort by (size, UL.x)) is reproduced exactly with an index-linked list.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+namespace dani {
+
+int cell_grid(int cols, int rows, std::vector<CellRect>& cells) {
+  cells.clear();
+  const float W = 35;
+  const int EDGE = 19;
+  const int minBorderX = EDGE - 3, minBorderY = minBorderX;
+  const int maxBorderX = cols - EDGE + 3, maxBorderY = rows - EDGE + 3;
+  const float width = (float)(maxBorderX - minBorderX), height = (float)(maxBorderY - minBorderY);
+  const int nCols = (int)(width / W), nRows = (int)(height / W);
+  if (nCols <= 0 || nRows <= 0) return 0;
+  const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+  for (int i = 0; i < nRows; i++) {
+    const float iniY = (float)(minBorderY + i * hCell);
+    float maxY = iniY + hCell + 6;
+    if (iniY >= maxBorderY - 3) continue;
+    if (maxY > maxBorderY) maxY = (float)maxBorderY;
+    for (int j = 0; j < nCols; j++) {
+      const float iniX = (float)(minBorderX + j * wCell);
+      float maxX = iniX + wCell + 6;
+      if (iniX >= maxBorderX - 6) continue;
+      if (maxX > maxBorderX) maxX = (float)maxBorderX;
+      CellRect c;
+      c.iniX = (int)iniX; c.maxX = (int)maxX; c.iniY = (int)iniY; c.maxY = (int)maxY;
+      c.offX = j * wCell; c.offY = i * hCell;
+      cells.push_back(c);
+    }
+  }
+  return (int)cells.size();
+}
+
+void features_per_level(int nfeatures, float scaleFactorF, int nlevels, std::vector<int>& per_level,
+                        std::vector<float>& scales) {
+  const double scaleFactor = (double)scaleFactorF;
+  scales.assign(nlevels, 1.0f);
+  for (int i = 1; i < nlevels; i++) scales[i] = (float)(scales[i - 1] * scaleFactor);
+  per_level.assign(nlevels, 0);
+  float factor = (float)(1.0f / scaleFactor);
+  float nDesired = (float)(nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels)));
+  int sum = 0;
+  for (int level = 0; level < nlevels - 1; level++) {
+    per_level[level] = (int)std::lrintf(nDesired);
+    sum += per_level[level];
+    nDesired *= factor;
+  }
+  per_level[nlevels - 1] = std::max(nfeatures - sum, 0);
+}
+
+namespace {
+
+struct QNode {
+  int ulx, uly, brx, bry;  // UL and BR corners (UR.x == BR.x, BL.y == BR.y for every node)
+  int kbeg, kcnt;          // key index range in the pool
+  int prev, next;          // list links
+  bool no_more;
+};
+
+struct QTree {
+  const HostKey* keys;
+  std::vector<QNode> nodes;
+  std::vector<int> pool;  // key indices, children are stable partitions of their parent
+  int head = -1, tail = -1, size = 0;
+
+  int new_node() { nodes.emplace_back(); return (int)nodes.size() - 1; }
+  void push_front(int n) {
+    nodes[n].prev = -1; nodes[n].next = head;
+    if (head >= 0) nodes[head].prev = n; else tail = n;
+    head = n; size++;
+  }
+  void push_back(int n) {
+    nodes[n].next = -1; nodes[n].prev = tail;
+    if (tail >= 0) nodes[tail].next = n; else head = n;
+    tail = n; size++;
+  }
+  int erase(int n) {  // returns the successor
+    const int p = nodes[n].prev, q = nodes[n].next;
+    if (p >= 0) nodes[p].next = q; else head = q;
+    if (q >= 0) nodes[q].prev = p; else tail = p;
+    size--;
+    return q;
+  }
+  // DivideNode: children ids in ch[0..3] (n1..n4), created but not linked
+  void divide(int parent, int ch[4]) {
+    const QNode P = nodes[parent];
+    const int halfX = (int)std::ceil(static_cast<float>(P.brx - P.ulx) / 2);
+    const int halfY = (int)std::ceil(static_cast<float>(P.bry - P.uly) / 2);
+    const int mx = P.ulx + halfX, my = P.uly + halfY;
+    for (int i = 0; i < 4; i++) ch[i] = new_node();
+    QNode& n1 = nodes[ch[0]]; QNode& n2 = nodes[ch[1]]; QNode& n3 = nodes[ch[2]]; QNode& n4 = nodes[ch[3]];
+    n1.ulx = P.ulx; n1.uly = P.uly; n1.brx = mx;    n1.bry = my;
+    n2.ulx = mx;    n2.uly = P.uly; n2.brx = P.brx; n2.bry = my;
+    n3.ulx = P.ulx; n3.uly = my;    n3.brx = mx;    n3.bry = P.bry;
+    n4.ulx = mx;    n4.uly = my;    n4.brx = P.brx; n4.bry = P.bry;
+    int cnt[4] = {0, 0, 0, 0};
+    const int beg = P.kbeg, end = P.kbeg + P.kcnt;
+    auto quadrant = [&](int k) {
+      const HostKey& kp = keys[k];
+      if (kp.x < (float)mx) return kp.y < (float)my ? 0 : 2;
+      return kp.y < (float)my ? 1 : 3;
+    };
+    for (int i = beg; i < end; i++) cnt[quadrant(pool[i])]++;
+    int start[4];
+    const int base = (int)pool.size();
+    start[0] = base; start[1] = start[0] + cnt[0]; start[2] = start[1] + cnt[1]; start[3] = start[2] + cnt[2];
+    pool.resize(base + P.kcnt);
+    int w[4] = {start[0], start[1], start[2], start[3]};
+    for (int i = beg; i < end; i++) { const int k = pool[i]; pool[w[quadrant(k)]++] = k; }
+    for (int i = 0; i < 4; i++) {
+      QNode& c = nodes[ch[i]];
+      c.kbeg = start[i]; c.kcnt = cnt[i]; c.no_more = (cnt[i] == 1); c.prev = c.next = -1;
+    }
+  }
+};
+
+}  // namespace
+
+void distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY, int maxY, int N,
+                        std::vector<int>& out_idx) {
+  out_idx.clear();
+  if (n <= 0) return;
+  QTree t;
+  t.keys = keys;
+  t.nodes.reserve(8 * (size_t)std::max(N, 64) + 64);
+  t.pool.reserve((size_t)n * 12);
+  const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+  const float hX = static_cast<float>(maxX - minX) / nIni;
+  // initial nodes + assignment (stable per node)
+  std::vector<int> which(n), cnt(std::max(nIni, 1), 0);
+  for (int i = 0; i < n; i++) { which[i] = (int)(keys[i].x / hX); cnt[which[i]]++; }
+  std::vector<int> start(nIni + 1, 0);
+  for (int i = 0; i < nIni; i++) start[i + 1] = start[i] + cnt[i];
+  t.pool.resize(n);
+  { std::vector<int> w(start.begin(), start.end() - 1); for (int i = 0; i < n; i++) t.pool[w[which[i]]++] = i; }
+  for (int i = 0; i < nIni; i++) {
+    const int id = t.new_node();
+    QNode& nd = t.nodes[id];
+    nd.ulx = (int)(hX * static_cast<float>(i)); nd.uly = 0;
+    nd.brx = (int)(hX * static_cast<float>(i + 1)); nd.bry = maxY - minY;
+    nd.kbeg = start[i]; nd.kcnt = cnt[i]; nd.no_more = false;
+    t.push_back(id);
+  }
+  for (int it = t.head; it >= 0;) {
+    QNode& nd = t.nodes[it];
+    if (nd.kcnt == 1) { nd.no_more = true; it = nd.next; }
+    else if (nd.kcnt == 0) it = t.erase(it);
+    else it = nd.next;
+  }
+
+  std::vector<std::pair<int, int>> expandable;  // (size, node id) in creation order
+  auto link_children = [&](const int ch[4], int* nToExpand) {
+    for (int i = 0; i < 4; i++) {
+      const int c = ch[i];
+      if (t.nodes[c].kcnt > 0) {
+        t.push_front(c);
+        if (t.nodes[c].kcnt > 1) {
+          if (nToExpand) (*nToExpand)++;
+          expandable.push_back(std::make_pair(t.nodes[c].kcnt, c));
+        }
+      }
+    }
+  };
+  auto cmp = [&](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+    if (a.first < b.first) return true;
+    if (a.first > b.first) return false;
+    return t.nodes[a.second].ulx < t.nodes[b.second].ulx;
+  };
+
+  bool finish = false;
+  while (!finish) {
+    int prevSize = t.size;
+    int nToExpand = 0;
+    expandable.clear();
+    for (int it = t.head; it >= 0;) {
+      if (t.nodes[it].no_more) { it = t.nodes[it].next; continue; }
+      int ch[4];
+      t.divide(it, ch);
+      link_children(ch, &nToExpand);
+      it = t.erase(it);
+    }
+    if (t.size >= N || t.size == prevSize) {
+      finish = true;
+    } else if (t.size + nToExpand * 3 > N) {
+      while (!finish) {
+        prevSize = t.size;
+        std::vector<std::pair<int, int>> prev = expandable;
+        expandable.clear();
+        std::sort(prev.begin(), prev.end(), cmp);
+        for (int j = (int)prev.size() - 1; j >= 0; j--) {
+          int ch[4];
+          t.divide(prev[j].second, ch);
+          link_children(ch, nullptr);
+          t.erase(prev[j].second);
+          if (t.size >= N) break;
+        }
+        if (t.size >= N || t.size == prevSize) finish = true;
+      }
+    }
+  }
+  out_idx.reserve(t.size);
+  for (int it = t.head; it >= 0; it = t.nodes[it].next) {
+    const QNode& nd = t.nodes[it];
+    int best = t.pool[nd.kbeg];
+    float maxResponse = keys[best].r;
+    for (int k = 1; k < nd.kcnt; k++) {
+      const int idx = t.pool[nd.kbeg + k];
+      if (keys[idx].r > maxResponse) { best = idx; maxResponse = keys[idx].r; }
+    }
+    out_idx.push_back(best);
+  }
+}
+
+}  // namespace dani

@@ -1,0 +1,153 @@
+/*
+ * dani_frontend.h -- C ABI of the MI355X-native front-end perception engine.
+ *
+ * This is the drop-in boundary for the reference's per-frame front-end.  The
+ * reference has no FFI layer: its boundary is three C++ classes built on LibTorch.  Each entry point
+ * below names the reference interface it replaces (paths relative to /root/reference); the C++17
+ * shims in include/dani_shims.hpp keep those class and method names on top of this ABI, and
+ * INTEGRATION.md shows the lines a maintainer changes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / OpenCV / HIP types cross this boundary;
+ *   - every function returns 0 (DANI_OK) or a negative dani_status; dani_last_error() gives text;
+ *     no C++ exception crosses the ABI;
+ *   - the caller owns and allocates all outputs; a too-small capacity returns DANI_ERR_CAPACITY and
+ *     writes the needed count to *n_out;
+ *   - an engine is bound to one GPU and may be used from several host threads at once (the reference
+ *     runs two extractors concurrently, src/Frame.cc:124-127): weights are shared read-only, every
+ *     call takes a private stream + workspace from the engine's pool;
+ *   - there is NO CPU fallback: without a usable MI355X, dani_engine_create fails with
+ *     DANI_ERR_NO_DEVICE.
+ */
+#ifndef DANI_FRONTEND_H
+#define DANI_FRONTEND_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DANI_API __attribute__((visibility("default")))
+
+typedef enum dani_status {
+  DANI_OK = 0,
+  DANI_ERR_INVALID = -1,     /* bad argument */
+  DANI_ERR_NO_DEVICE = -2,   /* no HIP device / wrong architecture */
+  DANI_ERR_HIP = -3,         /* a HIP runtime call failed */
+  DANI_ERR_WEIGHTS = -4,     /* missing / mis-shaped weight tensor (reference: std::exit, src/SPextractor.cpp:88-91) */
+  DANI_ERR_CAPACITY = -5,    /* output buffer too small, *n_out holds the needed count */
+  DANI_ERR_UNSUPPORTED = -6, /* configuration not implemented (e.g. nlevels > 1) */
+  DANI_ERR_EMPTY = -7        /* empty image (reference: operator() returns -1, src/SPextractor.cpp:135-136;
+                                Detect() returns false, src/YoloDetect.cpp:32-36) */
+} dani_status;
+
+typedef struct dani_engine dani_engine; /* opaque */
+
+typedef struct dani_config {
+  int32_t device;      /* HIP device ordinal */
+  int32_t max_batch;   /* largest B passed to the *_batch calls (>= 1) */
+  int32_t max_width;   /* largest image width  (e.g. 640) */
+  int32_t max_height;  /* largest image height (e.g. 480) */
+  int32_t n_contexts;  /* stream+workspace pool size = max concurrent calls (0 -> 2) */
+} dani_config;
+
+/* ---- life cycle -------------------------------------------------------------------------- */
+
+/* Replaces: SPextractor::SPextractor's torch::load (src/SPextractor.cpp:80-91), LightGlue::LightGlue's
+ * jit::load (src/LightGlue.cpp:7-12, paid per construction in the reference, quirk Q12) and
+ * YoloDetection::YoloDetection's jit::load (src/YoloDetect.cpp:6-20).  One engine per process and GPU;
+ * constructing the C++ shims afterwards is O(1). */
+DANI_API int dani_engine_create(const dani_config* cfg, dani_engine** out);
+DANI_API void dani_engine_destroy(dani_engine* e);
+DANI_API const char* dani_last_error(const dani_engine* e); /* e may be NULL: last create() error */
+
+/* Upload one named f32 tensor.  SuperPoint names/layouts are the reference's own parameter names
+ * (src/SuperPoint.cpp:37-52): "conv1a.weight" [64,1,3,3] ... "convDb.bias" [256], OIHW, i.e. what
+ * torch::save(model) holds.  tools/convert_weights.py turns a torch archive into these calls / a .dsw
+ * file.  `count` is the number of floats and is checked against the expected shape. */
+DANI_API int dani_set_tensor(dani_engine* e, const char* name, const float* data, int64_t count);
+/* Load every tensor of a .dsw container (tools/convert_weights.py). */
+DANI_API int dani_load_weights_file(dani_engine* e, const char* path);
+/* Called once after the last dani_set_tensor: packs weights into the kernels' layouts. */
+DANI_API int dani_finalize_weights(dani_engine* e);
+
+/* ---- SuperPoint extraction ---------------------------------------------------------------- */
+
+/* The reference's whole extractor configuration (ORBextractor.* YAML keys, src/Tracking.cc:590-602;
+ * iniThFAST/minThFAST are reinterpreted as SuperPoint probabilities, src/SPextractor.cpp:271,291). */
+typedef struct dani_sp_params {
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels;
+  float ini_th;
+  float min_th;
+} dani_sp_params;
+
+/* Replaces SPextractor::operator() (src/SPextractor.cpp:130-217) incl. ComputePyramid,
+ * ComputeKeyPointsOctTree, the per-cell getKeyPoints/NMS2 loop, the dynamic-box cull, DistributeOctTree
+ * and computeDescriptors.
+ *   img/stride : 8-bit gray, `stride` bytes per row (a non-contiguous cv::Mat ROI is fine)
+ *   boxes      : nboxes x (x, y, w, h) int32 = SPextractor::mvDynamicArea (src/SPextractor.h:69)
+ *   lapping    : vLappingArea[2]
+ *   kpts_xy    : cap x 2 (x, y) in level-0 pixel coordinates; resp: cap; octave: cap; size: cap
+ *   desc       : cap x 256 f32, row i belongs to keypoint i BEFORE the mono/stereo partition (the
+ *                reference does not permute descriptors with the keypoints, src/SPextractor.cpp:159 vs
+ *                :202-210 -- reproduced)
+ *   *n_out     : number of keypoints; *mono_index: operator()'s return value. */
+DANI_API int dani_sp_extract(dani_engine* e, const uint8_t* img, int32_t width, int32_t height, int32_t stride,
+                             const dani_sp_params* p, const int32_t* boxes, int32_t nboxes, const int32_t lapping[2],
+                             float* kpts_xy, float* resp, int32_t* octave, float* size, float* desc, int32_t cap,
+                             int32_t* n_out, int32_t* mono_index);
+
+/* Batched variant: B images of identical size.  `imgs` is a HOST pointer to B*height*stride bytes, or,
+ * with imgs_on_device != 0, a DEVICE pointer (frames already resident in HBM).  boxes are per frame:
+ * box_offsets has B+1 entries indexing into boxes.  Outputs are B slabs of `cap` entries each; n_out and
+ * mono_index have B entries. */
+DANI_API int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_device, int32_t B,
+                                   int32_t width, int32_t height, int32_t stride, const dani_sp_params* p,
+                                   const int32_t* boxes, const int32_t* box_offsets, const int32_t lapping[2],
+                                   float* kpts_xy, float* resp, int32_t* octave, float* size, float* desc,
+                                   int32_t cap, int32_t* n_out, int32_t* mono_index);
+
+/* Test / parity hooks: intermediate results of the LAST dani_sp_extract* call on this thread's context
+ * (frame b).  prob: height8 x width8 f32 (SPDetector::mProb, src/SuperPoint.cpp:206); desc_map: 256 x
+ * height/8 x width/8 f32 NCHW (mDesc, :207); cand: the ordered vToDistributeKeys list (x, y, response)
+ * in border-relative coordinates (src/SPextractor.cpp:306-312).  Any pointer may be NULL. */
+DANI_API int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* desc_map, float* cand_xyr,
+                                 int32_t cand_cap, int32_t* n_cand);
+/* Copy one layer's activation (post-ReLU, pre-pool; layer index 0..11 in forward order) of frame b of the
+ * last call to host as dense [C][H][W].  Layers 1, 3 and 5 (conv1b/2b/3b) are returned AFTER their fused
+ * 2x2 max-pool (the pre-pool tensor never exists in HBM). */
+DANI_API int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, int64_t count);
+
+/* Profiling switch: when on, HIP events are recorded around every conv layer of the next calls (on the
+ * context's own stream) and dani_layer_timings() returns the 12 per-layer durations in ms (forward order). */
+DANI_API int dani_set_profiling(dani_engine* e, int32_t on);
+DANI_API int dani_layer_timings(dani_engine* e, float* ms12);
+
+/* Per-stage device timings (ms) of the last call on this thread's context, measured with HIP events on
+ * the context's stream: [0] conv stack, [1] softmax+norm+cells, [2] host quadtree, [3] descriptors,
+ * [4] total.  Also used by bench.py for the roofline figure of the dominant kernel. */
+DANI_API int dani_last_timings(dani_engine* e, float* ms, int32_t n);
+
+/* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
+
+/* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.
+ * in_xyr: n x (x, y, response) border-relative; out_idx: indices into the input, in the reference's
+ * std::list order; returns the count (<= cap) or a negative status. */
+DANI_API int dani_host_distribute_octtree(const float* in_xyr, int32_t n, int32_t min_x, int32_t max_x, int32_t min_y,
+                                          int32_t max_y, int32_t n_features, int32_t* out_idx, int32_t cap);
+/* The cell grid of ComputeKeyPointsOctTree (src/SPextractor.cpp:232-266) for an image size: writes up to
+ * cap cells as (iniX, maxX, iniY, maxY, offX, offY) and returns the number of non-skipped cells. */
+DANI_API int dani_host_cell_grid(int32_t width, int32_t height, int32_t* cells6, int32_t cap);
+/* mnFeaturesPerLevel / mvScaleFactor tables (src/SPextractor.cpp:97-126). */
+DANI_API int dani_host_features_per_level(int32_t nfeatures, float scale_factor, int32_t nlevels, int32_t* per_level,
+                                          float* scale_factors);
+
+DANI_API const char* dani_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANI_FRONTEND_H */

@@ -1,0 +1,84 @@
+"""CPU: the product's host logic (libdani_frontend.so, no GPU call) against the oracle, and the ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dani_slam_amd import frontend
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dani_frontend.h")).read()
+    names = re.findall(r"DANI_API\s+[\w\s\*]+?\b(dani_\w+)\s*\(", hdr)
+    assert len(names) >= 15
+    lib = ctypes.CDLL(frontend.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dani_frontend.h but not exported"
+    assert b"gfx950" in frontend.load_library().dani_version()
+
+
+def test_cell_grid_640x480():
+    cells = frontend.host_cell_grid(640, 480)
+    assert len(cells) == 204                      # 12 x 17, SURVEY.md section 8 notation
+    w = cells[:, 1] - cells[:, 0]; h = cells[:, 3] - cells[:, 2]
+    assert w.max() == 42 and h.max() == 44
+    assert cells[0].tolist() == [16, 58, 16, 60, 0, 0]
+    assert cells[:, 1].max() == 624 and cells[:, 3].max() == 464
+    # the oracle walks the same cells: candidates of a flat prob map above threshold cover exactly these cells
+    for (W, H) in [(640, 480), (320, 240), (752, 480), (1280, 720)]:
+        c = frontend.host_cell_grid(W, H)
+        assert len(c) > 0 and (c[:, 1] - c[:, 0]).max() <= 64 and (c[:, 3] - c[:, 2]).max() <= 64
+
+
+def test_features_per_level_matches_oracle():
+    for nf, sf, nl in [(1024, 1.2, 1), (1000, 1.2, 8), (2000, 1.2, 8), (1250, 1.1, 4)]:
+        a, sa = frontend.host_features_per_level(nf, sf, nl)
+        b, sb = oracle.features_per_level(nf, sf, nl)
+        assert a.tolist() == b.tolist() and np.array_equal(sa, sb)
+        assert a.sum() >= nf - nl
+
+
+def _random_candidates(rng, n, w=608, h=448, clustered=False):
+    if clustered:
+        cx = rng.randint(0, w, 12); cy = rng.randint(0, h, 12)
+        k = rng.randint(0, 12, n)
+        x = np.clip(cx[k] + rng.randint(-25, 26, n), 0, w - 1)
+        y = np.clip(cy[k] + rng.randint(-25, 26, n), 0, h - 1)
+    else:
+        x = rng.randint(0, w, n); y = rng.randint(0, h, n)
+    r = rng.uniform(0.007, 1.0, n)
+    if n > 10:   # duplicates (overlap strips emit a pixel twice, quirk Q5) and response ties
+        x[5] = x[3]; y[5] = y[3]; r[7] = r[2]
+    return np.stack([x, y, r], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,N,clustered", [(0, 100, False), (1, 100, False), (2, 1, False), (7, 3, False),
+                                           (500, 1024, False), (3000, 1024, False), (3000, 1024, True),
+                                           (9000, 1024, False), (9000, 2000, True), (20000, 1000, False),
+                                           (1500, 1500, True), (4000, 300, False)])
+def test_quadtree_matches_oracle(n, N, clustered):
+    rng = np.random.RandomState(n + N)
+    for rep in range(3):
+        xyr = _random_candidates(rng, n, clustered=clustered)
+        ref = oracle.distribute_octtree(xyr, 16, 624, 16, 464, N)
+        idx = frontend.host_distribute_octtree(xyr, 16, 624, 16, 464, N)
+        got = xyr[idx] if len(idx) else np.zeros((0, 3), np.float32)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref)            # same points, same std::list order
+        if n:
+            assert len(idx) <= max(N + 3, 1) or len(idx) <= n
+
+
+def test_quadtree_other_aspect_ratios():
+    rng = np.random.RandomState(5)
+    for (minX, maxX, minY, maxY) in [(16, 736, 16, 464), (16, 1264, 16, 704), (16, 304, 16, 224)]:
+        w, h = maxX - minX, maxY - minY
+        xyr = _random_candidates(rng, 2500, w=w, h=h)
+        ref = oracle.distribute_octtree(xyr, minX, maxX, minY, maxY, 800)
+        idx = frontend.host_distribute_octtree(xyr, minX, maxX, minY, maxY, 800)
+        assert np.array_equal(xyr[idx], ref)

@@ -1,0 +1,158 @@
+"""GPU parity tests for the SuperPoint path: HIP engine (through the C ABI) vs the CPU oracle on the same
+seeded inputs.  Bar (BASELINE.json north_star): keypoint indices bit-exact, descriptors within 1e-3.
+Because the kernels evaluate the canonical f32 order with v_mfma_f32_32x32x2_f32 (an exact fmaf chain),
+we additionally assert BIT-EXACT prob maps, activations and descriptors (np.array_equal; +0 == -0)."""
+import numpy as np
+import pytest
+
+from dani_slam_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine(sp_weights):
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=4, max_width=640, max_height=480, weights=sp_weights)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def oracle_frames(sp_weights):
+    out = {}
+    for i in (0, 1, 2):
+        img = synth.frame(i)
+        out[i] = (img, oracle.sp_extract(img, sp_weights, want_maps=True))
+    return out
+
+
+def test_crop_every_layer_bit_exact(engine, sp_weights):
+    img = synth.frame(0)[96:96 + 96, 160:160 + 128].copy()      # 96 x 128 crop
+    prob_o, desc_o, taps = oracle.superpoint_forward(img, sp_weights, want_taps=True)
+    engine.sp_extract_batch(img[None])
+    for li, tp in enumerate(taps):
+        ref = oracle.maxpool2(tp) if li in (1, 3, 5) else tp    # pooled layers: fused pool output
+        got = engine.sp_debug_layer(0, li, ref.shape)
+        assert np.array_equal(got, ref), f"layer {li}: max abs diff {np.abs(got - ref).max()}"
+    prob, dmap, _ = engine.sp_debug_fetch(0, 96, 128)
+    assert np.array_equal(prob, prob_o)
+    assert np.array_equal(dmap, desc_o)
+
+
+def test_full_frame_prob_and_descmap_bit_exact(engine, oracle_frames):
+    img, ref = oracle_frames[0]
+    engine.sp_extract_batch(img[None])
+    prob, dmap, cand = engine.sp_debug_fetch(0, 480, 640)
+    assert np.array_equal(prob, ref["prob"])
+    assert np.array_equal(dmap, ref["desc_map"])
+    cand_ref = oracle.collect_candidates(ref["prob"], 640, 480, 0.015, 0.007)
+    assert np.array_equal(cand, cand_ref)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_extract_matches_oracle(engine, oracle_frames, i):
+    img, ref = oracle_frames[i]
+    r = engine.sp_extract_batch(img[None])[0]
+    assert r["kpts"].shape == ref["kpts"].shape
+    assert np.array_equal(r["kpts"], ref["kpts"])               # bit-exact keypoint coordinates and order
+    assert np.array_equal(r["resp"], ref["resp"])
+    assert r["mono_index"] == ref["mono_index"]
+    assert np.array_equal(r["octave"], ref["octave"]) and np.array_equal(r["size"], ref["size"])
+    np.testing.assert_allclose(r["desc"], ref["desc"], rtol=0, atol=1e-3)   # the stated bar
+    assert np.array_equal(r["desc"], ref["desc"])                             # what we actually hold
+
+
+def test_batch_equals_single(engine, oracle_frames):
+    imgs = np.stack([oracle_frames[i][0] for i in (0, 1, 2, 0)])
+    rs = engine.sp_extract_batch(imgs)
+    for b, i in enumerate((0, 1, 2, 0)):
+        ref = oracle_frames[i][1]
+        assert np.array_equal(rs[b]["kpts"], ref["kpts"])
+        assert np.array_equal(rs[b]["desc"], ref["desc"])
+
+
+def test_dynamic_boxes_and_lapping(engine, sp_weights, oracle_frames):
+    img = oracle_frames[1][0]
+    boxes = [(200, 120, 160, 240), (1, 1, 1, 1), (500, 300, 90, 120)]   # incl. the reference's placeholder box
+    ref = oracle.sp_extract(img, sp_weights, boxes=boxes, lapping=(0, 300))
+    r = engine.sp_extract_batch(img[None], boxes=[np.array(boxes)], lapping=(0, 300))[0]
+    assert np.array_equal(r["kpts"], ref["kpts"]) and r["mono_index"] == ref["mono_index"]
+    assert np.array_equal(r["desc"], ref["desc"])
+    inside = (r["kpts"][:, 0] >= 200) & (r["kpts"][:, 0] < 360) & (r["kpts"][:, 1] >= 120) & (r["kpts"][:, 1] < 360)
+    assert not inside.any()
+    assert 0 < r["mono_index"] < len(r["kpts"])
+
+
+def test_other_params_and_thresholds(engine, sp_weights, oracle_frames):
+    img = oracle_frames[2][0]
+    for nf, ini, mn in [(300, 0.015, 0.007), (2000, 0.02, 0.004), (1024, 0.5, 0.3)]:
+        ref = oracle.sp_extract(img, sp_weights, nfeatures=nf, iniTh=ini, minTh=mn)
+        r = engine.sp_extract_batch(img[None], nfeatures=nf, iniTh=ini, minTh=mn)[0]
+        assert np.array_equal(r["kpts"], ref["kpts"]), (nf, ini, mn)
+        assert np.array_equal(r["desc"], ref["desc"])
+
+
+def test_non_contiguous_stride_and_smaller_image(sp_weights):
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=1, max_width=640, max_height=480, weights=sp_weights)
+    big = synth.frame(3)
+    roi = big[40:40 + 240, 100:100 + 320]                      # non-contiguous ROI view, stride 640
+    ref = oracle.sp_extract(np.ascontiguousarray(roi), sp_weights, nfeatures=500)
+    lib = e.lib
+    import ctypes as C
+    cap = 600
+    k = np.empty((cap, 2), np.float32); rr = np.empty(cap, np.float32); o = np.empty(cap, np.int32)
+    sz = np.empty(cap, np.float32); d = np.empty((cap, 256), np.float32)
+    n = np.zeros(1, np.int32); mono = np.zeros(1, np.int32)
+    p = frontend._SpParams(500, 1.2, 1, 0.015, 0.007)
+    lap = np.zeros(2, np.int32)
+    ptr = C.c_void_p(big.ctypes.data + 40 * 640 + 100)
+    rc = lib.dani_sp_extract_batch(e.h, ptr, 0, 1, 320, 240, 640, C.byref(p), None, None, frontend._ip(lap),
+                                   frontend._fp(k), frontend._fp(rr), frontend._ip(o), frontend._fp(sz),
+                                   frontend._fp(d), cap, frontend._ip(n), frontend._ip(mono))
+    assert rc == 0, lib.dani_last_error(e.h)
+    assert np.array_equal(k[:n[0]], ref["kpts"]) and np.array_equal(d[:n[0]], ref["desc"])
+    e.close()
+
+
+def test_error_behaviour(engine, sp_weights):
+    from dani_slam_amd import frontend
+    img = synth.frame(0)
+    with pytest.raises(frontend.DaniError) as ei:
+        engine.sp_extract_batch(img[None], nlevels=8)           # not implemented -> loud error, no fallback
+    assert ei.value.code == frontend.DANI_ERR_UNSUPPORTED
+    with pytest.raises(frontend.DaniError) as ei:
+        engine.sp_extract_batch(img[None], cap=10)
+    assert ei.value.code == frontend.DANI_ERR_CAPACITY
+    ex = frontend.SPextractor(1024, 1.2, 1, 0.015, 0.007, engine=engine)
+    mono, kps, desc = ex(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and kps == [] and desc.shape == (0, 256)  # SPextractor.cpp:135-136
+    e2 = frontend.Engine(device=0)
+    with pytest.raises(frontend.DaniError) as ei:
+        e2.sp_extract_batch(img[None])                          # weights never set
+    assert ei.value.code == frontend.DANI_ERR_WEIGHTS
+    bad = dict(sp_weights); bad["conv3a.weight"] = bad["conv3a.weight"][:, :32]
+    with pytest.raises(frontend.DaniError) as ei:
+        e2.set_weights(bad)
+    assert ei.value.code == frontend.DANI_ERR_WEIGHTS
+    e2.close()
+
+
+def test_reference_style_wrapper(engine, oracle_frames):
+    from dani_slam_amd import frontend
+    img, ref = oracle_frames[0]
+    ex = frontend.SPextractor(1024, 1.2, 1, 0.015, 0.007, engine=engine)
+    assert ex.GetLevels() == 1 and abs(ex.GetScaleFactor() - 1.2) < 1e-6
+    mono, kps, desc = ex(img, None, (0, 0))
+    assert mono == ref["mono_index"] and len(kps) == len(ref["kpts"])
+    assert all(k.angle == -1.0 and k.size == 31.0 and k.octave == 0 for k in kps)   # quirk Q15
+    assert np.array_equal(np.array([[k.x, k.y] for k in kps], np.float32), ref["kpts"])
+
+
+def test_flat_image_no_crash(engine, sp_weights):
+    img = np.full((480, 640), 128, np.uint8)
+    ref = oracle.sp_extract(img, sp_weights)
+    r = engine.sp_extract_batch(img[None])[0]
+    assert np.array_equal(r["kpts"], ref["kpts"])
