@@ -1,0 +1,113 @@
+// dani_shims.hpp -- header-only C++17 shims that keep the reference's class names and method signatures on top
+// of the C ABI in dani_frontend.h.  They replace include/SPextractor.h (+ SuperPoint.h) of the reference; see
+// INTEGRATION.md.  This header needs OpenCV (cv::Mat, cv::KeyPoint) exactly like the headers it replaces and is
+// therefore compiled only inside the reference's build tree -- OpenCV is not present in this repo's image, so it
+// is NOT built or tested here (the Python mirror dani_slam_amd/frontend.py exercises the same ABI calls).
+#pragma once
+#include <opencv2/core/core.hpp>
+
+#include <cstdlib>
+#include <iostream>
+#include <mutex>
+#include <vector>
+
+#include "dani_frontend.h"
+
+namespace dani_shim {
+
+// Process-wide engine: weights are loaded once (the reference re-loads its TorchScript/archives per object
+// construction, quirk Q12: src/LGmatcher.cpp:39, src/Frame.cc:827).  DANI_WEIGHTS names the .dsw produced by
+// tools/convert_weights.py from /sly_slam/superpoint_new.pt (src/SPextractor.cpp:86).
+inline dani_engine* engine() {
+  static dani_engine* e = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    dani_config cfg{0, 8, 1280, 1024, 4};
+    const char* w = std::getenv("DANI_WEIGHTS");
+    if (dani_engine_create(&cfg, &e) != DANI_OK || dani_load_weights_file(e, w ? w : "/sly_slam/dani_frontend.dsw") != DANI_OK ||
+        dani_finalize_weights(e) != DANI_OK) {
+      // same behaviour as the reference on a model-load failure: src/SPextractor.cpp:88-91
+      std::cerr << "Error loading the model: " << dani_last_error(e) << std::endl;
+      std::exit(EXIT_FAILURE);
+    }
+  });
+  return e;
+}
+
+}  // namespace dani_shim
+
+namespace ORB_SLAM3 {
+
+// Replaces class SPextractor, include/SPextractor.h:24-96 (same public surface; no torch member).
+class SPextractor {
+ public:
+  SPextractor(int nfeatures_, float scaleFactor_, int nlevels_, float iniThFAST_, float minThFAST_)
+      : nfeatures(nfeatures_), scaleFactor(scaleFactor_), nlevels(nlevels_), iniThFAST(iniThFAST_), minThFAST(minThFAST_) {
+    dani_shim::engine();
+    std::cout << "[SPDetector::detect] Model loaded successfully." << std::endl;
+    mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    dani_host_features_per_level(nfeatures, scaleFactor_, nlevels, mnFeaturesPerLevel.data(), mvScaleFactor.data());
+    mvInvScaleFactor.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
+    for (int i = 0; i < nlevels; i++) {
+      mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+      mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+      mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+    }
+    mvImagePyramid.resize(nlevels);
+  }
+  ~SPextractor() {}
+
+  // src/SPextractor.cpp:130-217
+  int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                 cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+    if (_image.empty()) return -1;
+    cv::Mat image = _image.getMat();
+    CV_Assert(image.type() == CV_8UC1);
+    const int cap = nfeatures + 8;
+    std::vector<float> kxy(2 * cap), resp(cap), size(cap), desc((size_t)cap * 256);
+    std::vector<int32_t> octave(cap), boxes(4 * mvDynamicArea.size());
+    for (size_t i = 0; i < mvDynamicArea.size(); i++) {
+      boxes[4 * i] = mvDynamicArea[i].x; boxes[4 * i + 1] = mvDynamicArea[i].y;
+      boxes[4 * i + 2] = mvDynamicArea[i].width; boxes[4 * i + 3] = mvDynamicArea[i].height;
+    }
+    const dani_sp_params p{nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST};
+    const int32_t lap[2] = {vLappingArea[0], vLappingArea[1]};
+    int32_t n = 0, mono = 0;
+    const int rc = dani_sp_extract(dani_shim::engine(), image.data, image.cols, image.rows, (int)image.step, &p,
+                                   boxes.data(), (int)mvDynamicArea.size(), lap, kxy.data(), resp.data(),
+                                   octave.data(), size.data(), desc.data(), cap, &n, &mono);
+    if (rc != DANI_OK) { std::cerr << dani_last_error(dani_shim::engine()) << std::endl; std::exit(EXIT_FAILURE); }
+    if (n == 0) _descriptors.release();
+    else {
+      _descriptors.create(n, 256, CV_32F);
+      cv::Mat(n, 256, CV_32F, desc.data()).copyTo(_descriptors.getMat());
+    }
+    _keypoints = std::vector<cv::KeyPoint>(n);
+    for (int i = 0; i < n; i++)
+      _keypoints[i] = cv::KeyPoint(kxy[2 * i], kxy[2 * i + 1], size[i], -1, resp[i], octave[i]);
+    return mono;
+  }
+
+  int inline GetLevels() { return nlevels; }
+  float inline GetScaleFactor() { return scaleFactor; }
+  std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+  std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+  std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+  std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+  std::vector<cv::Mat> mvImagePyramid;       // kept for source compatibility (not filled: the pyramid lives in HBM)
+  std::vector<cv::Rect2i> mvDynamicArea;     // written by Tracking::GrabImageRGBD, src/Tracking.cc:1539
+
+ protected:
+  int nfeatures; double scaleFactor; int nlevels; float iniThFAST, minThFAST;
+  std::vector<int> mnFeaturesPerLevel;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+#ifndef ORB_SLAM3_ORBEXTRACTOR_DEFINED
+#define ORB_SLAM3_ORBEXTRACTOR_DEFINED
+typedef SPextractor ORBextractor;   // include/SPextractor.h:100
+#endif
+
+}  // namespace ORB_SLAM3
