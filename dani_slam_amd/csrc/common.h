@@ -81,6 +81,24 @@ void launch_descriptors(const float* desc_nhwc, int Hc, int Wc, int PH, int PW, 
                         float* out /*[B][cap][256]*/, hipStream_t s);
 void launch_copy_layer_dense(const ActDesc& a, int b, float* out_dense, hipStream_t s);
 
+// ---- LightGlue kernels (lg_kernels.hip) ------------------------------------------------------------
+struct LgSet { int tok_off, n, partner_off, partner_n; float size_w, size_h; };
+void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
+                      float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
+                      int rot_rows, float alpha, hipStream_t s);
+void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s);
+void launch_posenc(const float* kpts, const LgSet* sets, int nsets, int max_np, const float* wr, float* cosb,
+                   float* sinb, int ld, hipStream_t s);
+void launch_desc_to_fm(const float* desc_tm, const LgSet* sets, int nsets, int max_np, float* x, int ld, hipStream_t s);
+void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
+                      int max_n, int cross, float scale, hipStream_t s);
+void launch_matchability(const float* x, const float* w, float b, float* logsig, int T, int ld, hipStream_t s);
+void launch_sim(const float* md, int ld, const LgSet* sets, int npairs, int max_np, float* sim, int sim_ld,
+                size_t sim_pair_stride, hipStream_t s);
+void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const LgSet* sets, int npairs, int max_n,
+                             const float* logsig, float* lse_row, float* lse_col, int* m0, float* max0, int* m1, int ld,
+                             hipStream_t s);
+
 // ---- host logic --------------------------------------------------------------------------------
 struct HostKey { float x, y, r; };
 // DistributeOctTree (reference src/SPextractor.cpp:405-629); returns indices into `keys`, in list order.

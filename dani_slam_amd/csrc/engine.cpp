@@ -295,6 +295,10 @@ int dani_load_weights_file(dani_engine* e, const char* path) {
   return DANI_OK;
 }
 
+}  // extern "C"
+namespace { int lg_finalize(dani_engine* e); }
+extern "C" {
+
 int dani_finalize_weights(dani_engine* e) {
   if (!e) return DANI_ERR_INVALID;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -329,6 +333,7 @@ int dani_finalize_weights(dani_engine* e) {
     HIP_TRY(e, hipMemcpy(L.w_packed, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(L.bias_packed, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
   }
+  { int rc = lg_finalize(e); if (rc) return rc; }
   e->finalized = true;
   return DANI_OK;
 }
@@ -547,6 +552,341 @@ int dani_host_features_per_level(int32_t nfeatures, float scale_factor, int32_t 
   std::vector<int> f; std::vector<float> s;
   features_per_level(nfeatures, scale_factor, nlevels, f, s);
   for (int i = 0; i < nlevels; i++) { per_level[i] = f[i]; if (scale_factors) scale_factors[i] = s[i]; }
+  return DANI_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// LightGlue
+// ================================================================================================
+namespace {
+
+constexpr int LG_LAYERS = 9, LG_DIM = 256;
+
+struct LgLinear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
+struct LgBlockW { LgLinear a, b, c, ffn0, ffn3; float* ln_g = nullptr; float* ln_b = nullptr; };  // self: a=Wqkv,b=out_proj; cross: a=to_qk,b=to_v,c=to_out
+struct LgWeights {
+  bool ready = false;
+  float* wr = nullptr;
+  LgBlockW self_[LG_LAYERS], cross_[LG_LAYERS];
+  LgLinear final_proj;
+  float* match_w = nullptr;
+  float match_b = 0.0f;
+};
+
+struct LgContext {
+  int pairs = 0, kmax = 0, ld = 0, sim_ld = 0;
+  float *kpts = nullptr, *desc_tm = nullptr;  // token-major staging [ld][2], [ld][256]
+  LgSet* d_sets = nullptr;
+  float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *msg = nullptr, *hbuf = nullptr, *qk = nullptr, *v = nullptr;
+  float *cosb = nullptr, *sinb = nullptr, *md = nullptr, *logsig = nullptr, *lse_row = nullptr, *lse_col = nullptr, *max0 = nullptr;
+  int *m0 = nullptr, *m1 = nullptr;
+  float* sim = nullptr;
+  // pinned host
+  LgSet* h_sets = nullptr;
+  float* h_stage = nullptr;   // kpts + desc staging
+  int* h_m0 = nullptr; int* h_m1 = nullptr; float* h_max0 = nullptr;
+  std::vector<void*> dev_allocs, host_allocs;
+  int last_nsets = 0;
+  std::vector<LgSet> last_sets;
+};
+
+std::map<Context*, LgContext*> g_lg_ctx;  // guarded by engine mutex
+std::map<dani_engine*, LgWeights*> g_lg_w;
+
+LgWeights* lg_weights(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  auto it = g_lg_w.find(e);
+  if (it != g_lg_w.end()) return it->second;
+  LgWeights* w = new LgWeights();
+  g_lg_w[e] = w;
+  return w;
+}
+
+int lg_upload(dani_engine* e, const std::vector<float>& v, float** out) {
+  HIP_TRY(e, hipMalloc((void**)out, v.size() * 4));
+  e->weight_allocs.push_back(*out);
+  HIP_TRY(e, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// pack a torch Linear ([out, in] row-major) for linear_fm_kernel; `perm` optionally permutes output rows
+int lg_pack_linear(dani_engine* e, const std::string& name, int out, int in, LgLinear* L, const std::vector<int>* perm = nullptr) {
+  auto wi = e->tensors.find(name + ".weight"), bi = e->tensors.find(name + ".bias");
+  if (wi == e->tensors.end() || bi == e->tensors.end()) return fail(e, DANI_ERR_WEIGHTS, "missing tensor %s.weight/.bias", name.c_str());
+  if (wi->second.size() != (size_t)out * in || bi->second.size() != (size_t)out)
+    return fail(e, DANI_ERR_WEIGHTS, "tensor %s.weight has %zu floats, expected [%d,%d]", name.c_str(), wi->second.size(), out, in);
+  std::vector<float> w(wi->second), b(bi->second);
+  if (perm) {
+    std::vector<float> w2(w.size()), b2(b.size());
+    for (int r = 0; r < out; r++) {
+      memcpy(&w2[(size_t)r * in], &w[(size_t)(*perm)[r] * in], (size_t)in * 4);
+      b2[r] = b[(*perm)[r]];
+    }
+    w.swap(w2); b.swap(b2);
+  }
+  const int tiles = (out + 63) / 64;
+  std::vector<float> wp((size_t)tiles * 64 * in), bp((size_t)tiles * 64);
+  pack_conv_weights(w.data(), b.data(), in, out, 1, 32, 64, wp.data(), bp.data());
+  L->out = out; L->in = in;
+  int rc;
+  if ((rc = lg_upload(e, wp, &L->w))) return rc;
+  return lg_upload(e, bp, &L->b);
+}
+
+int lg_vec(dani_engine* e, const std::string& name, size_t n, float** out) {
+  auto it = e->tensors.find(name);
+  if (it == e->tensors.end() || it->second.size() != n) return fail(e, DANI_ERR_WEIGHTS, "missing or mis-shaped tensor %s", name.c_str());
+  return lg_upload(e, it->second, out);
+}
+
+int lg_finalize(dani_engine* e) {
+  LgWeights* W = lg_weights(e);
+  W->ready = false;
+  if (e->tensors.find("posenc.Wr.weight") == e->tensors.end()) return 0;  // LightGlue weights not supplied: SP-only engine
+  int rc;
+  if ((rc = lg_vec(e, "posenc.Wr.weight", 64, &W->wr))) return rc;
+  // Wqkv rows: reference order h*192 + d*3 + {q,k,v}  ->  kernel order {q,k,v}*256 + h*64 + d
+  std::vector<int> perm(768);
+  for (int which = 0; which < 3; which++)
+    for (int h = 0; h < 4; h++)
+      for (int d = 0; d < 64; d++) perm[which * 256 + h * 64 + d] = h * 192 + d * 3 + which;
+  for (int i = 0; i < LG_LAYERS; i++) {
+    const std::string ps = "transformers." + std::to_string(i) + ".self_attn", pc = "transformers." + std::to_string(i) + ".cross_attn";
+    LgBlockW& S = W->self_[i]; LgBlockW& C = W->cross_[i];
+    if ((rc = lg_pack_linear(e, ps + ".Wqkv", 768, 256, &S.a, &perm))) return rc;
+    if ((rc = lg_pack_linear(e, ps + ".out_proj", 256, 256, &S.b))) return rc;
+    if ((rc = lg_pack_linear(e, ps + ".ffn.0", 512, 512, &S.ffn0))) return rc;
+    if ((rc = lg_vec(e, ps + ".ffn.1.weight", 512, &S.ln_g))) return rc;
+    if ((rc = lg_vec(e, ps + ".ffn.1.bias", 512, &S.ln_b))) return rc;
+    if ((rc = lg_pack_linear(e, ps + ".ffn.3", 256, 512, &S.ffn3))) return rc;
+    if ((rc = lg_pack_linear(e, pc + ".to_qk", 256, 256, &C.a))) return rc;
+    if ((rc = lg_pack_linear(e, pc + ".to_v", 256, 256, &C.b))) return rc;
+    if ((rc = lg_pack_linear(e, pc + ".to_out", 256, 256, &C.c))) return rc;
+    if ((rc = lg_pack_linear(e, pc + ".ffn.0", 512, 512, &C.ffn0))) return rc;
+    if ((rc = lg_vec(e, pc + ".ffn.1.weight", 512, &C.ln_g))) return rc;
+    if ((rc = lg_vec(e, pc + ".ffn.1.bias", 512, &C.ln_b))) return rc;
+    if ((rc = lg_pack_linear(e, pc + ".ffn.3", 256, 512, &C.ffn3))) return rc;
+  }
+  const std::string pa = "log_assignment." + std::to_string(LG_LAYERS - 1);
+  if ((rc = lg_pack_linear(e, pa + ".final_proj", 256, 256, &W->final_proj))) return rc;
+  if ((rc = lg_vec(e, pa + ".matchability.weight", 256, &W->match_w))) return rc;
+  auto mb = e->tensors.find(pa + ".matchability.bias");
+  if (mb == e->tensors.end() || mb->second.size() != 1) return fail(e, DANI_ERR_WEIGHTS, "missing %s.matchability.bias", pa.c_str());
+  W->match_b = mb->second[0];
+  W->ready = true;
+  return 0;
+}
+
+int lg_dev(dani_engine* e, LgContext* L, void** p, size_t bytes) {
+  HIP_TRY(e, hipMalloc(p, bytes));
+  L->dev_allocs.push_back(*p);
+  HIP_TRY(e, hipMemset(*p, 0, bytes));
+  return 0;
+}
+int lg_host(dani_engine* e, LgContext* L, void** p, size_t bytes) {
+  HIP_TRY(e, hipHostMalloc(p, bytes, hipHostMallocDefault));
+  L->host_allocs.push_back(*p);
+  return 0;
+}
+
+int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) {
+  LgContext* L;
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    auto it = g_lg_ctx.find(c);
+    if (it == g_lg_ctx.end()) { L = new LgContext(); g_lg_ctx[c] = L; } else L = it->second;
+  }
+  *out = L;
+  if (L->pairs >= pairs && L->kmax >= kmax) return 0;
+  for (void* p : L->dev_allocs) (void)hipFree(p);
+  for (void* p : L->host_allocs) (void)hipHostFree(p);
+  L->dev_allocs.clear(); L->host_allocs.clear();
+  pairs = std::max(pairs, L->pairs); kmax = std::max(kmax, L->kmax);
+  const int np = round_up(kmax, 32);
+  const int ld = round_up(pairs * 2 * np + 128, 256);
+  int rc;
+#define LGA(ptr, rows) if ((rc = lg_dev(e, L, (void**)&(ptr), (size_t)(rows) * ld * 4))) return rc;
+  LGA(L->x, 256) LGA(L->qkv, 768) LGA(L->ctx, 256) LGA(L->msg, 256) LGA(L->hbuf, 512) LGA(L->qk, 256) LGA(L->v, 256)
+  LGA(L->cosb, 32) LGA(L->sinb, 32) LGA(L->md, 256) LGA(L->logsig, 1) LGA(L->lse_row, 1) LGA(L->lse_col, 1) LGA(L->max0, 1)
+  LGA(L->m0, 1) LGA(L->m1, 1) LGA(L->kpts, 2) LGA(L->desc_tm, 256)
+#undef LGA
+  L->sim_ld = round_up(np + 128, 64);
+  if ((rc = lg_dev(e, L, (void**)&L->sim, (size_t)pairs * (np + 64) * L->sim_ld * 4))) return rc;
+  if ((rc = lg_dev(e, L, (void**)&L->d_sets, sizeof(LgSet) * 2 * pairs))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_sets, sizeof(LgSet) * 2 * pairs))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_stage, (size_t)ld * 258 * 4))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_m0, (size_t)ld * 4))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_m1, (size_t)ld * 4))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_max0, (size_t)ld * 4))) return rc;
+  L->pairs = pairs; L->kmax = kmax; L->ld = ld;
+  return 0;
+}
+
+// the 9-layer forward + assignment statistics on stream s; inputs already in L->kpts / L->desc_tm / L->d_sets
+void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, hipStream_t s) {
+  const int ld = L->ld, max_np = round_up(max_n, 32);
+  launch_desc_to_fm(L->desc_tm, L->d_sets, nsets, max_np, L->x, ld, s);
+  launch_posenc(L->kpts, L->d_sets, nsets, max_np, W->wr, L->cosb, L->sinb, ld, s);
+  auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
+    launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
+  };
+  const float qk_scale = 0.35355339059327373f;  // (64^-0.5)^0.5 applied to both sides, as the public CrossBlock
+  for (int i = 0; i < LG_LAYERS; i++) {
+    const LgBlockW& S = W->self_[i]; const LgBlockW& C = W->cross_[i];
+    lin(S.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 512, 1.0f);
+    launch_attention(L->qkv, L->qkv + (size_t)256 * ld, L->qkv + (size_t)512 * ld, L->ctx, ld, L->d_sets, nsets, max_n, 0, 0.125f, s);
+    lin(S.b, L->ctx, 256, nullptr, 0, L->msg, nullptr, 0, 1.0f);
+    lin(S.ffn0, L->x, 256, L->msg, 256, L->hbuf, nullptr, 0, 1.0f);
+    launch_ln_gelu(L->hbuf, S.ln_g, S.ln_b, T, ld, s);
+    lin(S.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
+    lin(C.a, L->x, 256, nullptr, 0, L->qk, nullptr, 0, qk_scale);
+    lin(C.b, L->x, 256, nullptr, 0, L->v, nullptr, 0, 1.0f);
+    launch_attention(L->qk, L->qk, L->v, L->ctx, ld, L->d_sets, nsets, max_n, 1, 1.0f, s);
+    lin(C.c, L->ctx, 256, nullptr, 0, L->msg, nullptr, 0, 1.0f);
+    lin(C.ffn0, L->x, 256, L->msg, 256, L->hbuf, nullptr, 0, 1.0f);
+    launch_ln_gelu(L->hbuf, C.ln_g, C.ln_b, T, ld, s);
+    lin(C.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
+  }
+  lin(W->final_proj, L->x, 256, nullptr, 0, L->md, nullptr, 0, 0.25f);   // / d^0.25, d = 256
+  launch_matchability(L->x, W->match_w, W->match_b, L->logsig, T, ld, s);
+  const size_t pstride = (size_t)(round_up(L->kmax, 32) + 64) * L->sim_ld;
+  launch_sim(L->md, ld, L->d_sets, nsets / 2, max_np, L->sim, L->sim_ld, pstride, s);
+  launch_assignment_stats(L->sim, L->sim_ld, pstride, L->d_sets, nsets / 2, max_n, L->logsig, L->lse_row, L->lse_col,
+                          L->m0, L->max0, L->m1, ld, s);
+}
+
+thread_local LgContext* t_last_lg = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_device, const float* kpts0,
+                        const float* desc0, const int32_t* n0, const float* kpts1, const float* desc1, const int32_t* n1,
+                        const float* size0, const float* size1, float threshold, int32_t* matches, float* scores,
+                        int32_t cap, int32_t* k_out) {
+  if (!e) return DANI_ERR_INVALID;
+  if (P < 1 || !n0 || !n1 || !kpts0 || !kpts1 || !desc0 || !desc1 || !matches || !scores || !k_out || cap < 1 || in_cap < 1)
+    return fail(e, DANI_ERR_INVALID, "bad dani_lg_match argument");
+  LgWeights* W = lg_weights(e);
+  if (!e->finalized || !W->ready) return fail(e, DANI_ERR_WEIGHTS, "LightGlue weights not loaded/finalized");
+  int kmax = 1;
+  for (int p = 0; p < P; p++) {
+    if (n0[p] < 0 || n1[p] < 0 || n0[p] > in_cap || n1[p] > in_cap) return fail(e, DANI_ERR_INVALID, "pair %d: bad keypoint count", p);
+    kmax = std::max(kmax, std::max(n0[p], n1[p]));
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  Context* c = acquire(e);
+  if (!c) return fail(e, DANI_ERR_INVALID, "all contexts busy");
+  struct Releaser { dani_engine* e; Context* c; ~Releaser() { release(e, c); } } rel{e, c};
+  LgContext* L = nullptr;
+  int rc = lg_ensure(e, c, &L, P, kmax);
+  if (rc) return rc;
+  t_last_lg = L;
+  hipStream_t s = c->stream;
+  // token layout: set 2p = side 0 of pair p, set 2p+1 = side 1; each padded to a multiple of 32 tokens
+  int off = 0, max_n = 0;
+  L->last_sets.assign(2 * P, LgSet());
+  for (int p = 0; p < P; p++) {
+    LgSet& a = L->last_sets[2 * p]; LgSet& b = L->last_sets[2 * p + 1];
+    a.tok_off = off; a.n = n0[p]; off += round_up(std::max(n0[p], 1), 32);
+    b.tok_off = off; b.n = n1[p]; off += round_up(std::max(n1[p], 1), 32);
+    a.partner_off = b.tok_off; a.partner_n = b.n; b.partner_off = a.tok_off; b.partner_n = a.n;
+    max_n = std::max(max_n, std::max(a.n, b.n));
+  }
+  const int T = off;
+  // sizes: explicit (w,h) or 1 + max - min of the keypoints (needs host keypoints)
+  std::vector<float> hk;
+  auto host_kpts = [&](const float* k, int p, int n) -> const float* {
+    if (!on_device) return k + (size_t)p * in_cap * 2;
+    hk.resize((size_t)n * 2);
+    (void)hipMemcpy(hk.data(), k + (size_t)p * in_cap * 2, (size_t)n * 8, hipMemcpyDeviceToHost);
+    return hk.data();
+  };
+  for (int p = 0; p < P; p++)
+    for (int side = 0; side < 2; side++) {
+      LgSet& st = L->last_sets[2 * p + side];
+      const float* sz = side ? size1 : size0;
+      if (sz) { st.size_w = sz[0]; st.size_h = sz[1]; }
+      else {
+        const float* k = host_kpts(side ? kpts1 : kpts0, p, st.n);
+        float mnx = 3e38f, mny = 3e38f, mxx = -3e38f, mxy = -3e38f;
+        for (int i = 0; i < st.n; i++) { mnx = std::min(mnx, k[2 * i]); mxx = std::max(mxx, k[2 * i]); mny = std::min(mny, k[2 * i + 1]); mxy = std::max(mxy, k[2 * i + 1]); }
+        st.size_w = st.n ? 1.0f + (mxx - mnx) : 1.0f; st.size_h = st.n ? 1.0f + (mxy - mny) : 1.0f;
+      }
+    }
+  memcpy(L->h_sets, L->last_sets.data(), sizeof(LgSet) * 2 * P);
+  HIP_TRY(e, hipMemcpyAsync(L->d_sets, L->h_sets, sizeof(LgSet) * 2 * P, hipMemcpyHostToDevice, s));
+  for (int p = 0; p < P; p++)
+    for (int side = 0; side < 2; side++) {
+      const LgSet& st = L->last_sets[2 * p + side];
+      if (!st.n) continue;
+      const float* k = (side ? kpts1 : kpts0) + (size_t)p * in_cap * 2;
+      const float* d = (side ? desc1 : desc0) + (size_t)p * in_cap * 256;
+      const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+      HIP_TRY(e, hipMemcpyAsync(L->kpts + (size_t)st.tok_off * 2, k, (size_t)st.n * 8, kind, s));
+      HIP_TRY(e, hipMemcpyAsync(L->desc_tm + (size_t)st.tok_off * 256, d, (size_t)st.n * 1024, kind, s));
+    }
+  HIP_TRY(e, hipEventRecord(c->ev[0], s));
+  if (max_n > 0) lg_forward(W, L, 2 * P, max_n, T, s);
+  HIP_TRY(e, hipEventRecord(c->ev[1], s));
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(L->h_m0, L->m0, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(L->h_m1, L->m1, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(L->h_max0, L->max0, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  (void)hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]);
+  c->ms[4] = c->ms[0];
+  t_last_ctx = c;
+  // mutual check + thresholds (filter_matches of the model at 0.1, then LightGlue::filterMatches, src/LightGlue.cpp:98-122)
+  int status = DANI_OK;
+  for (int p = 0; p < P; p++) {
+    const LgSet& a = L->last_sets[2 * p]; const LgSet& b = L->last_sets[2 * p + 1];
+    int k = 0;
+    int32_t* mo = matches + (size_t)p * cap * 2;
+    float* so = scores + (size_t)p * cap;
+    if (a.n > 0 && b.n > 0)
+      for (int i = 0; i < a.n; i++) {
+        const int jj = L->h_m0[a.tok_off + i];
+        if (jj < 0 || jj >= b.n || L->h_m1[b.tok_off + jj] != i) continue;
+        const float ms = std::exp(L->h_max0[a.tok_off + i]);
+        if (!(ms > 0.1f) || !(ms > threshold)) continue;
+        if (k < cap) { mo[2 * k] = i; mo[2 * k + 1] = jj; so[k] = ms; }
+        k++;
+      }
+    k_out[p] = k;
+    if (k > cap) status = DANI_ERR_CAPACITY;
+  }
+  if (status != DANI_OK) return fail(e, status, "match capacity %d too small", cap);
+  return DANI_OK;
+}
+
+int dani_lg_match(dani_engine* e, const float* kpts0, const float* desc0, int32_t n0, const float* kpts1,
+                  const float* desc1, int32_t n1, const float* size0, const float* size1, float threshold,
+                  int32_t* matches, float* scores, int32_t cap, int32_t* k_out) {
+  if (n0 == 0 || n1 == 0) { if (k_out) *k_out = 0; return e ? DANI_OK : DANI_ERR_INVALID; }
+  const int in_cap = std::max(n0, n1);
+  return dani_lg_match_batch(e, 1, in_cap, 0, kpts0, desc0, &n0, kpts1, desc1, &n1, size0, size1, threshold, matches,
+                             scores, cap, k_out);
+}
+
+int dani_lg_debug_fetch(dani_engine* e, int32_t set, float* desc_out, int32_t* m0, float* max0, int32_t cap) {
+  LgContext* L = t_last_lg;
+  if (!e || !L || set < 0 || set >= (int)L->last_sets.size()) return fail(e, DANI_ERR_INVALID, "no previous LightGlue call on this thread");
+  const LgSet& st = L->last_sets[set];
+  if (st.n > cap) return fail(e, DANI_ERR_CAPACITY, "need %d", st.n);
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (desc_out) {
+    std::vector<float> tmp((size_t)256 * st.n);
+    for (int f = 0; f < 256; f++)
+      HIP_TRY(e, hipMemcpy(&tmp[(size_t)f * st.n], L->x + (size_t)f * L->ld + st.tok_off, (size_t)st.n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < st.n; i++)
+      for (int f = 0; f < 256; f++) desc_out[(size_t)i * 256 + f] = tmp[(size_t)f * st.n + i];
+  }
+  if (m0) memcpy(m0, L->h_m0 + st.tok_off, (size_t)st.n * 4);
+  if (max0) memcpy(max0, L->h_max0 + st.tok_off, (size_t)st.n * 4);
   return DANI_OK;
 }
 

@@ -1,0 +1,513 @@
+// lg_kernels.hip -- LightGlue on the gfx950 FP32 matrix cores.
+//
+// Replaces the TorchScript forward the reference runs on LibTorch-CPU inside LightGlue::matchDescriptors
+// (/root/reference/src/LightGlue.cpp:84; the network itself is the absent blob lightglue_scripted_v2.pt, so the
+// architecture is the published LightGlue/SuperPoint model restated in oracle/lg_oracle.py -- parity unpinned).
+//
+// Layout: every activation is FEATURE-MAJOR  [features][ld]  (ld = padded token count of the whole batch, all
+// keypoint sets concatenated, each set padded to a multiple of 32 tokens).  With tokens on the fast axis
+//   * a linear layer  Y^T[out][tok] = W[out][k] X^T[k][tok]  is exactly the 1x1-conv GEMM shape: weights are the
+//     MFMA A operand (one conflict-free ds_read_b32 per lane), tokens are the B operand, and the 32x32 accumulator
+//     has tokens on the lanes -> coalesced 128-B stores;
+//   * attention computes S^T = K Q^T so that a query's softmax statistics live on ONE lane pair (max / sum are
+//     16 in-lane ops + one shfl_xor 32), and the probabilities in the S^T accumulator ARE the B operand of the
+//     O^T = V^T P^T product register for register (no LDS round trip, no transposes).
+// All contractions use v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate); bound: MFMA.
+#include "common.h"
+
+namespace dani {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------
+// linear_fm_kernel:  Y[o][t] = epilogue( sum_k W[o][k] * X[k][t] + b[o] ),  X = concat(X0 rows, X1 rows).
+// Workgroup tile 64 outputs x 256 tokens; wave w owns tokens [64w, 64w+64) x 64 outputs = 2x2 accumulators.
+// K is streamed in chunks of 32 rows through LDS with register prefetch (same pipeline as conv_mfma_kernel).
+// Epilogues: rotary embedding on rows < rot_rows (Wqkv with rows pre-permuted to [q|k|v][head][d]),
+//            scale alpha, residual add.
+// ---------------------------------------------------------------------------------------------
+struct LinArgs {
+  const float* x0; const float* x1; int K0, K1;
+  const float* w; const float* bias;
+  float* y; const float* res; const float* cosb; const float* sinb;
+  int OUT, T, ld, rot_rows;
+  float alpha;
+};
+
+constexpr int LIN_KC = 32, LIN_TT = 256, LIN_NCO = 64;
+
+__global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[LIN_KC * LIN_TT + LIN_KC * LIN_NCO];
+  float* sX = lds;
+  float* sW = lds + LIN_KC * LIN_TT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int tok0 = blockIdx.x * LIN_TT, ot = blockIdx.y;
+  const int K = a.K0 + a.K1, nchunks = K / LIN_KC;
+  const float* wt = a.w + (size_t)ot * K * LIN_NCO;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float bv = a.bias[ot * LIN_NCO + cb * 32 + acc_row(r, h)];
+      acc[cb][0][r] = bv; acc[cb][1][r] = bv;
+    }
+
+  // staging: X chunk = 32 rows x 256 tokens = 2048 float4 (8 per thread); W chunk = 2048 floats = 512 float4 (2 per thread)
+  f32x4 px[8], pw[2];
+  int xoff[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int e = tid + 256 * u;
+    xoff[u] = (e >> 6) * a.ld + tok0 + 4 * (e & 63);   // row e/64, float4 column e%64
+  }
+#define LIN_PREFETCH(ch_)                                                                            \
+  {                                                                                                  \
+    const int k0_ = (ch_) * LIN_KC;                                                                  \
+    const float* src_ = (k0_ < a.K0) ? a.x0 + (size_t)k0_ * a.ld : a.x1 + (size_t)(k0_ - a.K0) * a.ld; \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) px[u] = *reinterpret_cast<const f32x4*>(src_ + xoff[u]); \
+    const f32x4* ws_ = reinterpret_cast<const f32x4*>(wt + (size_t)(ch_) * (LIN_KC * LIN_NCO));     \
+    pw[0] = ws_[tid]; pw[1] = ws_[tid + 256];                                                        \
+  }
+  const float* bA = sW + h * LIN_NCO + j;
+  const float* bB = sX + h * LIN_TT + wave * 64 + j;
+
+  LIN_PREFETCH(0);
+  for (int ch = 0; ch < nchunks; ch++) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; u++) reinterpret_cast<f32x4*>(sX)[tid + 256 * u] = px[u];
+    reinterpret_cast<f32x4*>(sW)[tid] = pw[0];
+    reinterpret_cast<f32x4*>(sW)[tid + 256] = pw[1];
+    __syncthreads();
+    if (ch + 1 < nchunks) LIN_PREFETCH(ch + 1);
+#pragma unroll
+    for (int kp = 0; kp < LIN_KC / 2; kp++) {
+      const float a0 = bA[(kp * 2) * LIN_NCO], a1 = bA[(kp * 2) * LIN_NCO + 32];
+      const float b0 = bB[(kp * 2) * LIN_TT], b1 = bB[(kp * 2) * LIN_TT + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+#undef LIN_PREFETCH
+
+#pragma unroll
+  for (int tb = 0; tb < 2; tb++) {
+    const int tok = tok0 + wave * 64 + tb * 32 + j;
+    const bool ok = tok < a.T;
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int row = ot * LIN_NCO + cb * 32 + acc_row(r, h);   // even; row+1 is register r+1
+        float v0 = acc[cb][tb][r], v1 = acc[cb][tb][r + 1];
+        if (row < a.rot_rows && ok) {
+          const int ip = (row & 63) >> 1;
+          const float c = a.cosb[(size_t)ip * a.ld + tok], s = a.sinb[(size_t)ip * a.ld + tok];
+          const float r0 = v0 * c - v1 * s, r1 = v1 * c + v0 * s;   // t*cos + rotate_half(t)*sin
+          v0 = r0; v1 = r1;
+        }
+        v0 *= a.alpha; v1 *= a.alpha;
+        if (ok && row < a.OUT) {
+          const size_t o0 = (size_t)row * a.ld + tok;
+          if (a.res) { v0 += a.res[o0]; }
+          a.y[o0] = v0;
+        }
+        if (ok && row + 1 < a.OUT) {
+          const size_t o1 = (size_t)(row + 1) * a.ld + tok;
+          if (a.res) { v1 += a.res[o1]; }
+          a.y[o1] = v1;
+        }
+      }
+  }
+}
+
+void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
+                      float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
+                      int rot_rows, float alpha, hipStream_t s) {
+  LinArgs a;
+  a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w_packed; a.bias = bias_packed; a.y = y; a.res = res;
+  a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;
+  dim3 grid((T + LIN_TT - 1) / LIN_TT, (OUT + LIN_NCO - 1) / LIN_NCO);
+  hipLaunchKernelGGL(linear_fm_kernel, grid, dim3(256), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm(512, eps 1e-5, affine) + exact GELU, in place on H [512][ld].  Block = 64 tokens x 4 feature quarters.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_gelu_kernel(float* hbuf, const float* gamma, const float* beta, int T, int ld) {
+  __shared__ float red[4][64];
+  const int lp = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int tok = blockIdx.x * 64 + lp;
+  const bool ok = tok < T;
+  float v[128];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 128; i++) {
+    v[i] = ok ? hbuf[(size_t)(q * 128 + i) * ld + tok] : 0.0f;
+    s += v[i];
+  }
+  red[q][lp] = s;
+  __syncthreads();
+  const float mean = (red[0][lp] + red[1][lp] + red[2][lp] + red[3][lp]) * (1.0f / 512.0f);
+  __syncthreads();
+  float s2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 128; i++) { const float d = v[i] - mean; s2 += d * d; }
+  red[q][lp] = s2;
+  __syncthreads();
+  const float var = (red[0][lp] + red[1][lp] + red[2][lp] + red[3][lp]) * (1.0f / 512.0f);
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  if (!ok) return;
+#pragma unroll
+  for (int i = 0; i < 128; i++) {
+    const int f = q * 128 + i;
+    const float y = (v[i] - mean) * rstd * gamma[f] + beta[f];
+    hbuf[(size_t)f * ld + tok] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+  }
+}
+
+void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(ln_gelu_kernel, dim3((T + 63) / 64), dim3(256), 0, s, hbuf, gamma, beta, T, ld);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Learnable-Fourier positional encoding: proj = Wr (32x2) . kpt_n ; tables cos/sin [32][ld].
+// Also performs LightGlue::normalizeKeypoints (src/LightGlue.cpp:28-51): k = (k - size/2) / (max(size)/2).
+// ---------------------------------------------------------------------------------------------
+__global__ void posenc_kernel(const float* kpts /*[ld][2] token-major*/, const LgSet* sets, int nsets, const float* wr,
+                              float* cosb, float* sinb, int ld) {
+  const int set = blockIdx.y;
+  const LgSet st = sets[set];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= ((st.n + 31) & ~31)) return;
+  const int tok = st.tok_off + i;
+  const float sx = st.size_w / 2.0f, sy = st.size_h / 2.0f;
+  const float scale = fmaxf(st.size_w, st.size_h) / 2.0f;
+  float x = 0.0f, y = 0.0f;
+  if (i < st.n) { x = (kpts[2 * tok] - sx) / scale; y = (kpts[2 * tok + 1] - sy) / scale; }
+#pragma unroll 4
+  for (int f = 0; f < 32; f++) {
+    const float p = wr[2 * f] * x + wr[2 * f + 1] * y;
+    cosb[(size_t)f * ld + tok] = cosf(p);
+    sinb[(size_t)f * ld + tok] = sinf(p);
+  }
+}
+
+void launch_posenc(const float* kpts, const LgSet* sets, int nsets, int max_np, const float* wr, float* cosb,
+                   float* sinb, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(posenc_kernel, dim3((max_np + 63) / 64, nsets), dim3(64), 0, s, kpts, sets, nsets, wr, cosb, sinb, ld);
+}
+
+// token-major [tok][256] descriptors -> feature-major [256][ld] (zero for padding tokens)
+__global__ __launch_bounds__(256) void desc_to_fm_kernel(const float* desc_tm, const LgSet* sets, float* x, int ld) {
+  __shared__ float tile[64][65];
+  const int set = blockIdx.z;
+  const LgSet st = sets[set];
+  const int np = (st.n + 31) & ~31;
+  const int t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+  if (t0 >= np) return;
+  const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
+  for (int k = 0; k < 16; k++) {
+    const int tl = rq + 4 * k, ti = t0 + tl;
+    tile[tl][c] = (ti < st.n) ? desc_tm[(size_t)(st.tok_off + ti) * 256 + f0 + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int k = 0; k < 16; k++) {
+    const int fl = rq + 4 * k, ti = t0 + c;
+    if (ti < np) x[(size_t)(f0 + fl) * ld + st.tok_off + ti] = tile[c][fl];
+  }
+}
+
+void launch_desc_to_fm(const float* desc_tm, const LgSet* sets, int nsets, int max_np, float* x, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(desc_to_fm_kernel, dim3((max_np + 63) / 64, 4, nsets), dim3(256), 0, s, desc_tm, sets, x, ld);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Flash-style attention in f32:  O = softmax(scale * Q K^T) V  for one head, one (query set, key set) pair per
+// blockIdx.z; self-attention uses the set's own tokens as keys, cross-attention the partner set's.
+// Workgroup = 128 queries (wave = 32 queries), key tiles of 32 staged through LDS (row stride 33: the K^T read is
+// key-contiguous, the V^T read walks d with stride 33 -> both conflict-free).
+// ---------------------------------------------------------------------------------------------
+constexpr int AT_STRIDE = 33;
+
+__global__ __launch_bounds__(256, 2) void attn_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
+                                                      const LgSet* sets, int cross, float scale) {
+  __shared__ float sK[64 * AT_STRIDE];
+  __shared__ float sV[64 * AT_STRIDE];
+  const LgSet st = sets[blockIdx.z];
+  const int q0 = blockIdx.x * 128;
+  if (q0 >= st.n) return;
+  const int head = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int k_off = cross ? st.partner_off : st.tok_off, k_n = cross ? st.partner_n : st.n;
+  const int qi = q0 + wave * 32 + j;                       // may exceed n (padding rows: computed, not stored)
+  const int qtok = st.tok_off + min(qi, ((st.n + 31) & ~31) - 1);
+  const float* Qh = Q + (size_t)head * 64 * ld;
+  const float* Kh = K + (size_t)head * 64 * ld + k_off;
+  const float* Vh = V + (size_t)head * 64 * ld + k_off;
+
+  float qreg[32];
+#pragma unroll
+  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * scale;
+
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
+  float m = -1e30f, l = 0.0f;
+
+  const int ntiles = (k_n + 31) / 32;
+  // staging: tile = 64 d x 32 keys; 512 float4 per matrix, 2 per thread
+  f32x4 pk[2], pv[2];
+  int soff[2], loff[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int e = tid + 256 * u, d = e >> 3, q4 = e & 7;
+    soff[u] = d * ld + 4 * q4;
+    loff[u] = d * AT_STRIDE + 4 * q4;
+  }
+#define AT_PREFETCH(kt_)                                                               \
+  {                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 2; u++) {                                    \
+      pk[u] = *reinterpret_cast<const f32x4*>(Kh + (size_t)soff[u] + (kt_) * 32);      \
+      pv[u] = *reinterpret_cast<const f32x4*>(Vh + (size_t)soff[u] + (kt_) * 32);      \
+    }                                                                                  \
+  }
+  AT_PREFETCH(0);
+  for (int kt = 0; kt < ntiles; kt++) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) { sK[loff[u] + c] = pk[u][c]; sV[loff[u] + c] = pv[u][c]; }
+    }
+    __syncthreads();
+    if (kt + 1 < ntiles) AT_PREFETCH(kt + 1);
+
+    // S^T[key][query] = sum_d K[key][d] Q[query][d]
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 32; t++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(2 * t + h) * AT_STRIDE + j], qreg[t], s, 0, 0, 0);
+
+    const int kbase = kt * 32;
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      if (kbase + acc_row(r, h) >= k_n) s[r] = -1e30f;
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __expf(m - m_new);
+    float ls = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { s[r] = __expf(s[r] - m_new); ls += s[r]; }
+    l = l * alpha + ls;
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    // O^T[d][query] += sum_key V[key][d] P[query][key]; P^T accumulator register r is the B operand of step r
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int key = acc_row(r, h);
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[j * AT_STRIDE + key], s[r], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(32 + j) * AT_STRIDE + key], s[r], o[1], 0, 0, 0);
+    }
+  }
+#undef AT_PREFETCH
+  const float lt = l + __shfl_xor(l, 32);
+  const float inv = 1.0f / lt;
+  if (qi < st.n) {
+    float* Oh = O + (size_t)head * 64 * ld + st.tok_off + qi;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) Oh[(size_t)(db * 32 + acc_row(r, h)) * ld] = o[db][r] * inv;
+  }
+}
+
+void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
+                      int max_n, int cross, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(attn_kernel, dim3((max_n + 127) / 128, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, cross, scale);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MatchAssignment: matchability logit -> logsigmoid;  sim = md0^T md1 per pair;  log-double-softmax statistics;
+// row / column argmax of  scores = log_softmax_row(sim) + log_softmax_col(sim) + logsig(z0) + logsig(z1).
+// ---------------------------------------------------------------------------------------------
+__global__ void matchability_kernel(const float* x, const float* w, float b, float* logsig, int T, int ld) {
+  const int tok = blockIdx.x * 64 + threadIdx.x;
+  if (tok >= T) return;
+  float z = b;
+  for (int f = 0; f < 256; f++) z += w[f] * x[(size_t)f * ld + tok];
+  logsig[tok] = -(fmaxf(-z, 0.0f) + log1pf(__expf(-fabsf(z))));
+}
+void launch_matchability(const float* x, const float* w, float b, float* logsig, int T, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(matchability_kernel, dim3((T + 63) / 64), dim3(64), 0, s, x, w, b, logsig, T, ld);
+}
+
+// sim[pair][i][j] = sum_d md[d][off0+i] * md[d][off1+j]; tile 64 (i) x 128 (j): wave w -> j block pair? 4 waves = 2x2 of 32x64
+__global__ __launch_bounds__(256, 2) void sim_kernel(const float* md, int ld, const LgSet* sets, float* sim, int sim_ld,
+                                                     size_t sim_pair_stride) {
+  __shared__ __attribute__((aligned(16))) float lds[32 * 64 + 32 * 128];
+  float* sA = lds;            // [32 k][64 i]
+  float* sB = lds + 32 * 64;  // [32 k][128 j]
+  const int pair = blockIdx.z;
+  const LgSet s0 = sets[2 * pair], s1 = sets[2 * pair + 1];
+  const int np0 = (s0.n + 31) & ~31, np1 = (s1.n + 31) & ~31;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 128;
+  if (i0 >= np0 || j0 >= np1) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int wi = wave >> 1, wj = wave & 1;   // wave tile: 32 i x 64 j
+  f32x16 acc[2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+  for (int k0 = 0; k0 < 256; k0 += 32) {
+    __syncthreads();
+    // A: 32 x 64 floats = 512 float4 (2/thread); B: 32 x 128 = 1024 float4 (4/thread)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int e = tid + 256 * u, kk = e >> 4, c4 = e & 15;
+      reinterpret_cast<f32x4*>(sA)[e] = *reinterpret_cast<const f32x4*>(md + (size_t)(k0 + kk) * ld + s0.tok_off + i0 + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int e = tid + 256 * u, kk = e >> 5, c4 = e & 31;
+      reinterpret_cast<f32x4*>(sB)[e] = *reinterpret_cast<const f32x4*>(md + (size_t)(k0 + kk) * ld + s1.tok_off + j0 + 4 * c4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kp = 0; kp < 16; kp++) {
+      const float av = sA[(2 * kp + h) * 64 + wi * 32 + j];
+      const float b0 = sB[(2 * kp + h) * 128 + wj * 64 + j], b1 = sB[(2 * kp + h) * 128 + wj * 64 + 32 + j];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+    }
+  }
+  float* sp = sim + (size_t)pair * sim_pair_stride;
+#pragma unroll
+  for (int jb = 0; jb < 2; jb++) {
+    const int jj = j0 + wj * 64 + jb * 32 + j;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int ii = i0 + wi * 32 + acc_row(r, h);
+      if (ii < np0 && jj < np1) sp[(size_t)ii * sim_ld + jj] = acc[jb][r];
+    }
+  }
+}
+
+void launch_sim(const float* md, int ld, const LgSet* sets, int npairs, int max_np, float* sim, int sim_ld,
+                size_t sim_pair_stride, hipStream_t s) {
+  hipLaunchKernelGGL(sim_kernel, dim3((max_np + 127) / 128, (max_np + 63) / 64, npairs), dim3(256), 0, s, md, ld, sets,
+                     sim, sim_ld, sim_pair_stride);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// row statistics: lse_row[i] = max_j + log sum_j exp(sim - max) over valid j.  One wave per row.
+__global__ __launch_bounds__(64) void row_lse_kernel(const float* sim, int sim_ld, size_t pstride, const LgSet* sets,
+                                                     float* lse_row, int ld) {
+  const int pair = blockIdx.y, i = blockIdx.x;
+  const LgSet s0 = sets[2 * pair], s1 = sets[2 * pair + 1];
+  if (i >= s0.n) return;
+  const float* row = sim + (size_t)pair * pstride + (size_t)i * sim_ld;
+  float mx = -1e30f;
+  for (int jj = threadIdx.x; jj < s1.n; jj += 64) mx = fmaxf(mx, row[jj]);
+  mx = wave_max(mx);
+  float sm = 0.0f;
+  for (int jj = threadIdx.x; jj < s1.n; jj += 64) sm += __expf(row[jj] - mx);
+  sm = wave_sumf(sm);
+  if (threadIdx.x == 0) lse_row[s0.tok_off + i] = mx + __logf(sm);
+}
+
+// column statistics + column argmax of (2*sim - lse_row[i] + ls0[i]): thread per column, 4-way row split per block
+__global__ __launch_bounds__(256) void col_stats_kernel(const float* sim, int sim_ld, size_t pstride, const LgSet* sets,
+                                                        const float* lse_row, const float* logsig, float* lse_col,
+                                                        int* m1, int ld) {
+  __shared__ float rmx[4][64], rsm[4][64], rbv[4][64];
+  __shared__ int rbi[4][64];
+  const int pair = blockIdx.y;
+  const LgSet s0 = sets[2 * pair], s1 = sets[2 * pair + 1];
+  const int lj = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int jj = blockIdx.x * 64 + lj;
+  const bool ok = jj < s1.n;
+  const float* sp = sim + (size_t)pair * pstride + (ok ? jj : 0);
+  // pass 1: max over rows (online logsumexp) and best score
+  float mx = -1e30f, sm = 0.0f, bv = -3e38f;
+  int bi = 0;
+  for (int i = q; i < s0.n; i += 4) {
+    const float v = sp[(size_t)i * sim_ld];
+    const float nm = fmaxf(mx, v);
+    sm = sm * __expf(mx - nm) + __expf(v - nm);
+    mx = nm;
+    const float sc = 2.0f * v - lse_row[s0.tok_off + i] + logsig[s0.tok_off + i];
+    if (sc > bv) { bv = sc; bi = i; }
+  }
+  rmx[q][lj] = mx; rsm[q][lj] = sm; rbv[q][lj] = bv; rbi[q][lj] = bi;
+  __syncthreads();
+  if (q == 0 && ok) {
+    float M = rmx[0][lj];
+    for (int k = 1; k < 4; k++) M = fmaxf(M, rmx[k][lj]);
+    float S = 0.0f;
+    for (int k = 0; k < 4; k++) S += rsm[k][lj] * __expf(rmx[k][lj] - M);
+    lse_col[s1.tok_off + jj] = M + __logf(S);
+    float B = rbv[0][lj]; int I = rbi[0][lj];
+    for (int k = 1; k < 4; k++)
+      if (rbv[k][lj] > B || (rbv[k][lj] == B && rbi[k][lj] < I)) { B = rbv[k][lj]; I = rbi[k][lj]; }
+    m1[s1.tok_off + jj] = I;
+  }
+}
+
+// row argmax of scores and the score value itself.  One wave per row; first maximum wins ties.
+__global__ __launch_bounds__(64) void row_argmax_kernel(const float* sim, int sim_ld, size_t pstride, const LgSet* sets,
+                                                        const float* lse_row, const float* lse_col, const float* logsig,
+                                                        int* m0, float* max0) {
+  const int pair = blockIdx.y, i = blockIdx.x;
+  const LgSet s0 = sets[2 * pair], s1 = sets[2 * pair + 1];
+  if (i >= s0.n) return;
+  const float* row = sim + (size_t)pair * pstride + (size_t)i * sim_ld;
+  const float ri = lse_row[s0.tok_off + i], zi = logsig[s0.tok_off + i];
+  float bv = -3e38f;
+  int bj = 0x7fffffff;
+  for (int jj = threadIdx.x; jj < s1.n; jj += 64) {
+    const float v = row[jj];
+    const float sc = (v - ri) + (v - lse_col[s1.tok_off + jj]) + (zi + logsig[s1.tok_off + jj]);
+    if (sc > bv) { bv = sc; bj = jj; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oj = __shfl_xor(bj, off);
+    if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+  }
+  if (threadIdx.x == 0) { m0[s0.tok_off + i] = bj; max0[s0.tok_off + i] = bv; }
+}
+
+void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const LgSet* sets, int npairs, int max_n,
+                             const float* logsig, float* lse_row, float* lse_col, int* m0, float* max0, int* m1, int ld,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(row_lse_kernel, dim3(max_n, npairs), dim3(64), 0, s, sim, sim_ld, pstride, sets, lse_row, ld);
+  hipLaunchKernelGGL(col_stats_kernel, dim3((max_n + 63) / 64, npairs), dim3(256), 0, s, sim, sim_ld, pstride, sets, lse_row,
+                     logsig, lse_col, m1, ld);
+  hipLaunchKernelGGL(row_argmax_kernel, dim3(max_n, npairs), dim3(64), 0, s, sim, sim_ld, pstride, sets, lse_row, lse_col,
+                     logsig, m0, max0);
+}
+
+}  // namespace dani

@@ -74,6 +74,9 @@ def load_library():
                                           C.c_int32, _i32, _i32]
     lib.dani_sp_debug_fetch.argtypes = [C.c_void_p, C.c_int32, _f, _f, _f, C.c_int32, _i32]
     lib.dani_sp_debug_layer.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int64]
+    lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
+                                        C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
+    lib.dani_lg_debug_fetch.argtypes = [C.c_void_p, C.c_int32, _f, _i32, _f, C.c_int32]
     lib.dani_host_distribute_octtree.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.c_int32, _i32, C.c_int32]
     lib.dani_host_cell_grid.argtypes = [C.c_int32, C.c_int32, _i32, C.c_int32]
@@ -209,6 +212,50 @@ class Engine:
         self._check(self.lib.dani_sp_debug_layer(self.h, b, layer, _fp(out), out.size))
         return out
 
+    # -- LightGlue -------------------------------------------------------------------------------
+    def lg_match_batch(self, kpts0, desc0, n0, kpts1, desc1, n1, size0=None, size1=None, threshold=0.05, cap=None,
+                       device_ptrs=None, in_cap=None):
+        """P pairs.  Host arrays kpts [P, in_cap, 2], desc [P, in_cap, 256], counts n0/n1 [P]; or
+        device_ptrs=(kpts0, desc0, kpts1, desc1) raw device addresses with in_cap given.
+        Returns a list of (matches [K,2] int32, scores [K] f32)."""
+        n0 = np.ascontiguousarray(n0, np.int32).reshape(-1); n1 = np.ascontiguousarray(n1, np.int32).reshape(-1)
+        P = len(n0)
+        if device_ptrs is None:
+            kpts0 = np.ascontiguousarray(kpts0, np.float32); kpts1 = np.ascontiguousarray(kpts1, np.float32)
+            desc0 = np.ascontiguousarray(desc0, np.float32); desc1 = np.ascontiguousarray(desc1, np.float32)
+            in_cap = kpts0.shape[1]
+            assert kpts1.shape[1] == in_cap and desc0.shape[1] == in_cap and desc1.shape[1] == in_cap
+            ptrs = [a.ctypes.data_as(C.c_void_p) for a in (kpts0, desc0, kpts1, desc1)]
+            on_dev = 0
+        else:
+            ptrs = [C.c_void_p(p) for p in device_ptrs]
+            on_dev = 1
+        cap = cap or max(1, int(max(n0.max(), 1)))
+        m = np.empty((P, cap, 2), np.int32); sc = np.empty((P, cap), np.float32); k = np.zeros(P, np.int32)
+        s0 = np.asarray(size0, np.float32) if size0 is not None else None
+        s1 = np.asarray(size1, np.float32) if size1 is not None else None
+        rc = self.lib.dani_lg_match_batch(self.h, P, in_cap, on_dev, ptrs[0], ptrs[1], _ip(n0), ptrs[2], ptrs[3], _ip(n1),
+                                          _fp(s0) if s0 is not None else None, _fp(s1) if s1 is not None else None,
+                                          C.c_float(threshold), _ip(m), _fp(sc), cap, _ip(k))
+        self._check(rc)
+        return [(m[p, :k[p]].copy(), sc[p, :k[p]].copy()) for p in range(P)]
+
+    def lg_match(self, kpts0, desc0, kpts1, desc1, size0=None, size1=None, threshold=0.05):
+        kpts0 = np.asarray(kpts0, np.float32).reshape(-1, 2); kpts1 = np.asarray(kpts1, np.float32).reshape(-1, 2)
+        n0, n1 = len(kpts0), len(kpts1)
+        if n0 == 0 or n1 == 0:
+            return np.zeros((0, 2), np.int32), np.zeros(0, np.float32)
+        cap = max(n0, n1)
+        def pad(a, w):
+            out = np.zeros((1, cap, w), np.float32); out[0, :len(a)] = np.asarray(a, np.float32).reshape(-1, w); return out
+        return self.lg_match_batch(pad(kpts0, 2), pad(desc0, 256), [n0], pad(kpts1, 2), pad(desc1, 256), [n1],
+                                   size0, size1, threshold)[0]
+
+    def lg_debug_fetch(self, set_index, n):
+        d = np.empty((n, 256), np.float32); m0 = np.empty(n, np.int32); mx = np.empty(n, np.float32)
+        self._check(self.lib.dani_lg_debug_fetch(self.h, set_index, _fp(d), _ip(m0), _fp(mx), n))
+        return d, m0, mx
+
     def set_profiling(self, on=True):
         self._check(self.lib.dani_set_profiling(self.h, int(on)))
 
@@ -279,3 +326,32 @@ class SPextractor:
         kps = [KeyPoint(float(x), float(y), float(s), -1.0, float(rr), int(o))
                for (x, y), s, rr, o in zip(r["kpts"], r["size"], r["resp"], r["octave"])]
         return r["mono_index"], kps, r["desc"]
+
+
+@dataclass
+class DMatch:
+    """cv::DMatch as LightGlue::filterMatches fills it (src/LightGlue.cpp:114-119): distance = match confidence."""
+    queryIdx: int
+    trainIdx: int
+    distance: float
+
+
+class LightGlue:
+    """Mirror of ORB_SLAM3::LightGlue (include/LightGlue.h:11-36).  Construction is O(1): the weights live in the
+    process-wide engine (the reference jit::loads the blob in every constructor, quirk Q12)."""
+
+    def __init__(self, engine: Engine | None = None):
+        self.engine = engine or default_engine()
+
+    def matchDescriptors(self, keypoints1, descriptors1, keypoints2, descriptors2, size1=None, size2=None,
+                         threshold=0.05):
+        """keypoints: sequences of KeyPoint (or [n,2] arrays); descriptors [n,256]; size = (w, h) or None/empty.
+        Returns a list of DMatch, in increasing queryIdx order like the reference."""
+        def xy(k):
+            if len(k) and hasattr(k[0], "x"):
+                return np.array([[p.x, p.y] for p in k], np.float32)
+            return np.asarray(k, np.float32).reshape(-1, 2)
+        s1 = None if size1 is None or len(size1) == 0 else size1
+        s2 = None if size2 is None or len(size2) == 0 else size2
+        m, s = self.engine.lg_match(xy(keypoints1), descriptors1, xy(keypoints2), descriptors2, s1, s2, threshold)
+        return [DMatch(int(a), int(b), float(c)) for (a, b), c in zip(m, s)]

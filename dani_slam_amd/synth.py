@@ -81,3 +81,68 @@ def frame_bgr(i: int, width: int = 640, height: int = 480) -> np.ndarray:
     g = frame(i, width, height).astype(np.float64)
     gains = (0.9, 1.0, 0.8)
     return np.stack([np.clip(np.rint(g * s), 0, 255) for s in gains], axis=-1).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LightGlue: seeded synthetic weights under the public checkpoint's tensor names (the reference's network is the
+# absent TorchScript blob /sly_slam/lightglue_scripted_v2.pt, /root/reference/src/LightGlue.cpp:9).
+# ---------------------------------------------------------------------------------------------------------
+LG_LAYERS, LG_DIM, LG_HEADS = 9, 256, 4
+
+
+def lightglue_weights(seed: int = 0, block_gain: float = 0.5, proj_gain: float = 24.0) -> dict:
+    """Random transformer blocks (variance-preserving, residual branches scaled by `block_gain`) and an
+    assignment head close to a scaled identity, so that descriptors of corresponding points stay similar through
+    the 9 layers and the log-double-softmax produces a realistic number of confident mutual matches."""
+    rng = np.random.RandomState(1000 + seed)
+    d = LG_DIM
+    w = {}
+
+    def lin(name, out, inp, gain=1.0, bias=0.02):
+        w[name + ".weight"] = (rng.standard_normal((out, inp)) * (gain / np.sqrt(inp))).astype(np.float32)
+        w[name + ".bias"] = (rng.standard_normal(out) * bias).astype(np.float32)
+
+    w["posenc.Wr.weight"] = rng.standard_normal((32, 2)).astype(np.float32)
+    for i in range(LG_LAYERS):
+        for blk in ("self_attn", "cross_attn"):
+            p = f"transformers.{i}.{blk}"
+            if blk == "self_attn":
+                lin(p + ".Wqkv", 3 * d, d, gain=2.0)
+                lin(p + ".out_proj", d, d)
+            else:
+                lin(p + ".to_qk", d, d, gain=2.0)
+                lin(p + ".to_v", d, d)
+                lin(p + ".to_out", d, d)
+            lin(p + ".ffn.0", 2 * d, 2 * d)
+            w[p + ".ffn.1.weight"] = (1.0 + 0.1 * rng.standard_normal(2 * d)).astype(np.float32)
+            w[p + ".ffn.1.bias"] = (0.05 * rng.standard_normal(2 * d)).astype(np.float32)
+            lin(p + ".ffn.3", d, 2 * d, gain=block_gain * 0.06)
+        p = f"log_assignment.{i}"
+        w[p + ".final_proj.weight"] = (proj_gain * np.eye(d) + 0.5 * rng.standard_normal((d, d))).astype(np.float32)
+        w[p + ".final_proj.bias"] = (0.02 * rng.standard_normal(d)).astype(np.float32)
+        w[p + ".matchability.weight"] = (0.5 * rng.standard_normal((1, d))).astype(np.float32)
+        w[p + ".matchability.bias"] = np.array([2.0], np.float32)
+    return w
+
+
+def matching_pair(seed: int, n0: int = 1024, n1: int = 1024, overlap: float = 0.8, noise: float = 0.08,
+                  width: int = 640, height: int = 480):
+    """Synthetic keypoint/descriptor sets with known correspondences, in SuperPoint's output scale (each
+    descriptor column has unit norm over the keypoints, quirk Q7, so rows have norm ~ sqrt(256/n)).
+    Returns kpts0 [n0,2], desc0 [n0,256], kpts1 [n1,2], desc1 [n1,256], gt (index in set 1 for each of set 0, or -1)."""
+    rng = np.random.RandomState(777 + seed)
+    k0 = np.stack([rng.randint(16, width - 16, n0), rng.randint(16, height - 16, n0)], 1).astype(np.float32)
+    d0 = rng.standard_normal((n0, 256))
+    n_common = int(min(n0, n1) * overlap)
+    perm = rng.permutation(n1)
+    src = rng.permutation(n0)[:n_common]
+    k1 = np.stack([rng.randint(16, width - 16, n1), rng.randint(16, height - 16, n1)], 1).astype(np.float32)
+    d1 = rng.standard_normal((n1, 256))
+    gt = -np.ones(n0, np.int64)
+    for a, b in zip(src, perm[:n_common]):
+        d1[b] = d0[a] + noise * rng.standard_normal(256)
+        k1[b] = k0[a] + np.array([8.0, 0.0]) + rng.randint(-2, 3, 2)
+        gt[a] = b
+    d0 = d0 / np.linalg.norm(d0, axis=0, keepdims=True)
+    d1 = d1 / np.linalg.norm(d1, axis=0, keepdims=True)
+    return k0, d0.astype(np.float32), k1, d1.astype(np.float32), gt

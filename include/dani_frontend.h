@@ -131,6 +131,36 @@ DANI_API int dani_layer_timings(dani_engine* e, float* ms12);
  * [4] total.  Also used by bench.py for the roofline figure of the dominant kernel. */
 DANI_API int dani_last_timings(dani_engine* e, float* ms, int32_t n);
 
+/* ---- LightGlue matching -------------------------------------------------------------------- */
+
+/* Replaces LightGlue::matchDescriptors + normalizeKeypoints + filterMatches (src/LightGlue.cpp:18-122), as
+ * called from Frame::ComputeStereoMatches (src/Frame.cc:860), LGmatcher::SearchByBoW (src/LGmatcher.cpp:314) and
+ * LGmatcher::SearchForTriangulation (src/LGmatcher.cpp:983).  The torch::Tensor arguments of the reference become
+ * pointer + count (north_star: no LibTorch at run time).
+ *   kpts0/1 : n x 2 (x, y) = cv::KeyPoint::pt;  desc0/1 : n x 256 f32 (rows of the extractor's descriptor Mat)
+ *   size0/1 : (w, h) as the reference's size1/size2 tensors, or NULL -> 1 + max - min of the keypoints
+ *             (the size.numel()==0 branch, src/LightGlue.cpp:34-36)
+ *   threshold : filterMatches threshold (default 0.05 in include/LightGlue.h:23)
+ *   matches : cap x 2 int32 (queryIdx, trainIdx);  scores : cap f32 (= cv::DMatch::distance);  *k_out : count.
+ * Weight tensors use the public LightGlue checkpoint names (posenc.Wr.weight, transformers.{i}.self_attn.Wqkv.weight,
+ * ..., log_assignment.{i}.final_proj.weight) through dani_set_tensor / the .dsw file. */
+DANI_API int dani_lg_match(dani_engine* e, const float* kpts0, const float* desc0, int32_t n0, const float* kpts1,
+                           const float* desc1, int32_t n1, const float* size0, const float* size1, float threshold,
+                           int32_t* matches, float* scores, int32_t cap, int32_t* k_out);
+
+/* Batched variant: P independent pairs.  Inputs are P slabs of `in_cap` keypoints (the layout
+ * dani_sp_extract_batch writes: kpts [P][in_cap][2], desc [P][in_cap][256]); n0/n1 have P entries.  With
+ * on_device != 0 the kpts/desc pointers are DEVICE pointers.  size0/size1: (w, h) applied to every pair, or NULL.
+ * Outputs: matches [P][cap][2], scores [P][cap], k_out [P]. */
+DANI_API int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_device, const float* kpts0,
+                                 const float* desc0, const int32_t* n0, const float* kpts1, const float* desc1,
+                                 const int32_t* n1, const float* size0, const float* size1, float threshold,
+                                 int32_t* matches, float* scores, int32_t cap, int32_t* k_out);
+
+/* Test hook: final descriptors (after the 9 layers) of keypoint set `set` (2*pair + side) of the last LightGlue
+ * call on this thread, as [n][256] f32, and the raw row results (best column and log-score per query row). */
+DANI_API int dani_lg_debug_fetch(dani_engine* e, int32_t set, float* desc_out, int32_t* m0, float* max0, int32_t cap);
+
 /* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
 
 /* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.
