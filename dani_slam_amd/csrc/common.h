@@ -20,6 +20,7 @@ struct ActDesc {
   float* p = nullptr;
   int C = 0, H = 0, W = 0;  // logical dims
   int Hp = 0, Wp = 0;       // padded plane dims
+  int pady = PADY;          // top padding rows (2 for the input of the 6x6 stride-2 YOLO stem)
   size_t frame_stride() const { return (size_t)C * Hp * Wp; }
   size_t bytes(int B) const { return frame_stride() * B * sizeof(float); }
 };
@@ -37,11 +38,23 @@ enum ConvVariant {
   CONV3_ROW32_RELU_POOL = 1,  // same + fused 2x2 max-pool
   CONV3_BLK16_RELU = 2,       // 3x3, wave = 4 rows x 16 cols, WG tile 16x16, 64 couts, ReLU (1/8-res layers)
   CONV1_BLK16_LINEAR = 3,     // 1x1, WG tile 16x16, 64 couts, no activation
+  // YOLOv5s (SiLU): 6x6 stride-2 stem, 3x3 stride-2, 3x3, 1x1; "ROW32" = 8x32 tiles, "BLK16" = 16x16 tiles
+  CONV6S2_ROW32_SILU = 4, CONV3S2_ROW32_SILU = 5, CONV3S2_BLK16_SILU = 6, CONV3_ROW32_SILU = 7,
+  CONV3_BLK16_SILU = 8, CONV1_ROW32_SILU = 9, CONV1_BLK16_SILU = 10,
+};
+
+// tensor views for one conv launch: tensors may be channel slices of larger (concat) buffers
+struct ConvIO {
+  const float* in = nullptr; float* out = nullptr; const float* res = nullptr;
+  int H = 0, W = 0;                      // conv output dims (before fused pooling)
+  int iHp = 0, iWp = 0, ipady = PADY, oHp = 0, oWp = 0, opady = PADY;
+  size_t in_fs = 0, out_fs = 0, res_fs = 0;
 };
 
 struct ConvLayerPlan {
   ConvVariant variant;
   int Cin, Cout, ksize;
+  int CinPad = 0;        // Cin rounded up to the chunk size (the YOLO stem pads 3 -> 4 with a zero plane)
   int cout_tiles;        // ceil(Cout / 64)
   int CC;                // input channels per LDS chunk
   float* w_packed = nullptr;  // device, [cout_tile][chunk][cp][tap][cc][64]
@@ -52,13 +65,16 @@ struct ConvLayerPlan {
 // host-side packing of OIHW weights into the kernel layout
 void pack_conv_weights(const float* w_oihw, const float* bias, int Cin, int Cout, int ksize, int CC, int NCO,
                        float* w_packed, float* bias_packed);
-inline int conv_variant_cc(ConvVariant v) { return v == CONV1_BLK16_LINEAR ? 32 : 8; }
+inline int conv_variant_cc(ConvVariant v) {
+  return (v == CONV1_BLK16_LINEAR || v == CONV1_ROW32_SILU || v == CONV1_BLK16_SILU) ? 32 : (v == CONV6S2_ROW32_SILU ? 4 : 8);
+}
 
 // ---- kernel launchers (all asynchronous on `s`) ------------------------------------------------
 // conv1a: u8 image -> 64-channel padded planar, fused /255 + 3x3 conv + bias + ReLU (VALU kernel).
 void launch_conv1a(const uint8_t* img, int B, int H, int W, int stride, size_t img_frame_stride, const float* w /*64*9*/,
                    const float* bias /*64*/, const ActDesc& out, hipStream_t s);
 void launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s);
+void launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s);
 const char* conv_kernel_name(ConvVariant v);
 
 // semi [B][65(+pad)][..] padded planar -> prob [B][PH][PW] dense
@@ -98,6 +114,20 @@ void launch_sim(const float* md, int ld, const LgSet* sets, int npairs, int max_
 void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const LgSet* sets, int npairs, int max_n,
                              const float* logsig, float* lse_row, float* lse_col, int* m0, float* max0, int* m1, int ld,
                              hipStream_t s);
+
+// ---- YOLO kernels (yolo_kernels.hip) ---------------------------------------------------------------
+void launch_yolo_preproc(const uint8_t* bgr, int B, int sw, int sh, int sstride, size_t sframe, const ActDesc& out,
+                         hipStream_t s);
+void launch_maxpool5(const float* in, float* out, int C, int H, int W, int Hp, int Wp, size_t fs, int B, hipStream_t s);
+void launch_upsample2(const float* src, int sHp, int sWp, size_t sfs, float* dst, int C, int Hd, int Wd, int dHp, int dWp,
+                      size_t dfs, int B, hipStream_t s);
+void launch_yolo_decode(const float* raw, int ny, int nx, int Hp, int Wp, size_t fs, int level, int level_base,
+                        float score_thresh, float* cand, int* cand_count, int cand_cap, int B, hipStream_t s);
+// host: greedy class-agnostic NMS of the reference (src/YoloDetect.cpp:95-144) on candidate records of 8 floats
+int yolo_nms_host(const float* cand8, int n, float iou_thresh, float* dets6, int cap);
+// host: Detect()'s box bookkeeping + RefineDynamicBoxes (src/YoloDetect.cpp:51-80, 148-208)
+int yolo_dynamic_areas(const float* dets6, int n, int cols, int rows, const char* const* class_names, int n_classes,
+                       const char* const* dynamic_names, int n_dynamic, int32_t* det_rects, int32_t* dyn_boxes, int cap);
 
 // ---- host logic --------------------------------------------------------------------------------
 struct HostKey { float x, y, r; };

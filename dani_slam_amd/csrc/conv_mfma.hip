@@ -18,6 +18,7 @@
 // the next chunk is prefetched global->VGPR while the current one feeds the MFMAs, and 2-4 workgroups
 // per CU cover each other's barriers.  Roofline: MFMA-bound (arithmetic intensity of a tile is ~80 FLOP/B
 // against L2, >1000 FLOP/B against HBM).
+#include "canon_math.h"
 #include "common.h"
 
 namespace dani {
@@ -30,28 +31,34 @@ struct ConvArgs {
   const float* w;      // packed
   const float* bias;   // packed
   float* out;
-  int Cin, Cout, H, W; // logical conv dims (output dims before pooling)
-  int iHp, iWp, oHp, oWp;
+  const float* res;    // optional residual (same plane geometry as out), added after the activation
+  int Cin, Cout, H, W; // Cin = (padded) input channels; H, W = OUTPUT dims before pooling
+  int iHp, iWp, ipady, oHp, oWp, opady;
+  size_t in_fs, out_fs, res_fs;   // per-frame strides in floats (tensors may be channel slices of concat buffers)
   int tiles_x, tiles_y, cout_tiles, nchunks;
 };
 
-template <int KS_, int PBH_, int PBW_, int NPB_, int CC_, bool RELU_, bool POOL_>
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
+
+template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_>
 struct Cfg {
-  static constexpr int KS = KS_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_;
-  static constexpr bool RELU = RELU_, POOL = POOL_;
+  static constexpr int KS = KS_, S = S_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_, ACT = ACT_;
+  static constexpr bool POOL = POOL_;
   static constexpr int T = KS * KS;
+  static constexpr int PAD = (KS == 1) ? 0 : (KS == 3) ? 1 : 2;   // 1x1 p0, 3x3 p1, 6x6 p2 (YOLOv5 stem)
   static constexpr int NCB = 2, NCO = 64;
-  static constexpr int TH = 4 * NPB * PBH, TW = PBW;   // 4 waves stacked vertically
-  static constexpr int HALO = KS / 2;
-  static constexpr int LROWS = TH + 2 * HALO;
-  static constexpr int RS = (KS == 3) ? TW + 8 : TW;   // LDS row stride; 3x3 stages columns x0-4 .. x0+TW+3
-  static constexpr int XOFF = (KS == 3) ? 3 : 0;       // LDS column of pixel px under tap kx = px + kx + XOFF
+  static constexpr int TH = 4 * NPB * PBH, TW = PBW;   // 4 waves stacked vertically (output pixels)
+  static constexpr int LROWS = S * (TH - 1) + KS;
+  static constexpr int XOFF = (KS == 1) ? 0 : PADX - PAD;          // LDS column of input col (S*px + kx - PAD)
+  static constexpr int RS = (XOFF + S * (TW - 1) + KS + 3) / 4 * 4; // LDS row stride (floats), 16-B multiple
+  static constexpr int GX0 = (KS == 1) ? PADX : 0;                 // first staged padded column minus S*x0
   static constexpr int IN_F4 = CC * LROWS * (RS / 4);
   static constexpr int W_F4 = CC * T * NCO / 4;
   static constexpr int NI = (IN_F4 + 255) / 256, NW = (W_F4 + 255) / 256;
   static constexpr int LDS_FLOATS = CC * LROWS * RS + CC * T * NCO;
   static_assert(PBH * PBW == 32, "a pixel block is one MFMA column block");
-  static_assert(!POOL || (PBH == 1 && NPB == 2), "fused pooling needs 2 image rows per wave");
+  static_assert(!POOL || (PBH == 1 && NPB == 2 && S == 1), "fused pooling needs 2 image rows per wave");
+  static_assert(LDS_FLOATS * 4 <= 65536, "LDS budget per workgroup");
 };
 
 template <class C>
@@ -71,10 +78,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   const int y0 = ty * C::TH, x0 = tx * C::TW;
 
   const size_t iplane = (size_t)a.iHp * a.iWp;
-  const float* inb = a.in + (size_t)b * a.Cin * iplane;
-  // first staged element: 3x3 -> padded (row y0, col x0) == pixel (y0-1, x0-4); 1x1 -> pixel (y0, x0)
-  const int gy0 = (C::KS == 3) ? y0 : y0 + PADY;
-  const int gx0 = (C::KS == 3) ? x0 : x0 + PADX;
+  const float* inb = a.in + (size_t)b * a.in_fs;
+  // first staged element (padded coordinates): row S*y0 + ipady - PAD, column S*x0 + GX0
+  const int gy0 = C::S * y0 + a.ipady - C::PAD;
+  const int gx0 = C::S * x0 + C::GX0;
   const float* wt = a.w + (size_t)ct * a.nchunks * (C::W_F4 * 4);
 
   // per-thread staging offsets (independent of the chunk)
@@ -107,14 +114,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   {                                                                                          \
     const float* src_ = inb + (size_t)(ch_) * C::CC * iplane;                                \
     _Pragma("unroll") for (int t = 0; t < C::NI; t++)                                        \
-      pin[t] = *reinterpret_cast<const f32x4*>(src_ + goff[t]);                           \
+      pin[t] = *reinterpret_cast<const f32x4*>(src_ + goff[t]);                              \
     const f32x4* wsrc_ = reinterpret_cast<const f32x4*>(wt + (size_t)(ch_) * (C::W_F4 * 4)); \
     _Pragma("unroll") for (int t = 0; t < C::NW; t++)                                        \
-      pw[t] = wsrc_[woff[t]];                                                              \
+      pw[t] = wsrc_[woff[t]];                                                                \
   }
 
   const float* bA = sW + h * C::NCO + j;
-  const float* bB = sIn + (h * C::LROWS + wave * C::NPB * C::PBH + j / C::PBW) * C::RS + (j % C::PBW) + C::XOFF;
+  const float* bB = sIn + (h * C::LROWS + C::S * (wave * C::NPB * C::PBH + j / C::PBW)) * C::RS + C::S * (j % C::PBW) + C::XOFF;
 
   DANI_PREFETCH(0);
   for (int ch = 0; ch < a.nchunks; ch++) {
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
           for (int cb = 0; cb < C::NCB; cb++) av[cb] = bA[((cp * C::T + ky * C::KS + kx) * 2) * C::NCO + cb * 32];
 #pragma unroll
-          for (int pb = 0; pb < C::NPB; pb++) bv[pb] = bB[(2 * cp * C::LROWS + pb * C::PBH + ky) * C::RS + kx];
+          for (int pb = 0; pb < C::NPB; pb++) bv[pb] = bB[(2 * cp * C::LROWS + C::S * pb * C::PBH + ky) * C::RS + kx];
 #pragma unroll
           for (int cb = 0; cb < C::NCB; cb++)
 #pragma unroll
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 #undef DANI_PREFETCH
   // ---- epilogue ----
   const size_t oplane = (size_t)a.oHp * a.oWp;
-  float* outb = a.out + (size_t)b * a.Cout * oplane;
+  float* outb = a.out + (size_t)b * a.out_fs;
   if constexpr (C::POOL) {
     const int yo = (y0 + wave * 2) >> 1, xo = (x0 + j) >> 1;
     const bool ok = ((j & 1) == 0) && yo < (a.H >> 1) && xo < (a.W >> 1);
@@ -160,11 +167,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
       for (int r = 0; r < 16; r++) {
         float m = fmaxf(acc[cb][0][r], acc[cb][1][r]);
         m = fmaxf(m, __shfl_xor(m, 1));
-        if (C::RELU) m = m > 0.0f ? m : 0.0f;
+        if (C::ACT == ACT_RELU) m = m > 0.0f ? m : 0.0f;
         const int co = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (ok && co < a.Cout) outb[(size_t)co * oplane + (size_t)(yo + PADY) * a.oWp + xo + PADX] = m;
+        if (ok && co < a.Cout) outb[(size_t)co * oplane + (size_t)(yo + a.opady) * a.oWp + xo + PADX] = m;
       }
   } else {
+    const float* resb = a.res ? a.res + (size_t)b * a.res_fs : nullptr;
 #pragma unroll
     for (int pb = 0; pb < C::NPB; pb++) {
       const int y = y0 + wave * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
@@ -174,56 +182,88 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           float v = acc[cb][pb][r];
-          if (C::RELU) v = v > 0.0f ? v : 0.0f;
+          if (C::ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
+          if (C::ACT == ACT_SILU) v = v / (1.0f + dani_expf(-v));
           const int co = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (ok && co < a.Cout) outb[(size_t)co * oplane + (size_t)(y + PADY) * a.oWp + x + PADX] = v;
+          if (ok && co < a.Cout) {
+            const size_t o = (size_t)co * oplane + (size_t)(y + a.opady) * a.oWp + x + PADX;
+            if (resb) v = resb[o] + v;
+            outb[o] = v;
+          }
         }
     }
   }
 }
 
-using CfgRow32Relu = Cfg<3, 1, 32, 2, 8, true, false>;
-using CfgRow32ReluPool = Cfg<3, 1, 32, 2, 8, true, true>;
-using CfgBlk16Relu = Cfg<3, 2, 16, 2, 8, true, false>;
-using CfgConv1Blk16 = Cfg<1, 2, 16, 2, 32, false, false>;
+//                         KS S PBH PBW NPB CC  ACT       POOL
+using CfgRow32Relu      = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, false>;
+using CfgRow32ReluPool  = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true>;
+using CfgBlk16Relu      = Cfg<3, 1, 2, 16, 2, 8, ACT_RELU, false>;
+using CfgConv1Blk16     = Cfg<1, 1, 2, 16, 2, 32, ACT_NONE, false>;
+// YOLOv5s variants (SiLU)
+using CfgStem6Row32     = Cfg<6, 2, 1, 32, 2, 4, ACT_SILU, false>;
+using CfgS2Row32Silu    = Cfg<3, 2, 1, 32, 2, 8, ACT_SILU, false>;
+using CfgS2Blk16Silu    = Cfg<3, 2, 2, 16, 2, 8, ACT_SILU, false>;
+using CfgRow32Silu      = Cfg<3, 1, 1, 32, 2, 8, ACT_SILU, false>;
+using CfgBlk16Silu      = Cfg<3, 1, 2, 16, 2, 8, ACT_SILU, false>;
+using CfgConv1Row32Silu = Cfg<1, 1, 1, 32, 2, 32, ACT_SILU, false>;
+using CfgConv1Blk16Silu = Cfg<1, 1, 2, 16, 2, 32, ACT_SILU, false>;
 
 template <class C>
-static void launch_cfg(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s) {
+static void launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
   ConvArgs a;
-  a.in = in.p; a.w = L.w_packed; a.bias = L.bias_packed; a.out = out.p;
-  a.Cin = L.Cin; a.Cout = L.Cout; a.H = in.H; a.W = in.W;
-  a.iHp = in.Hp; a.iWp = in.Wp; a.oHp = out.Hp; a.oWp = out.Wp;
-  a.tiles_x = (in.W + C::TW - 1) / C::TW;
-  a.tiles_y = (in.H + C::TH - 1) / C::TH;
+  a.in = io.in; a.w = L.w_packed; a.bias = L.bias_packed; a.out = io.out; a.res = io.res;
+  a.Cin = L.CinPad; a.Cout = L.Cout; a.H = io.H; a.W = io.W;
+  a.iHp = io.iHp; a.iWp = io.iWp; a.ipady = io.ipady; a.oHp = io.oHp; a.oWp = io.oWp; a.opady = io.opady;
+  a.in_fs = io.in_fs; a.out_fs = io.out_fs; a.res_fs = io.res_fs;
+  a.tiles_x = (io.W + C::TW - 1) / C::TW;
+  a.tiles_y = (io.H + C::TH - 1) / C::TH;
   a.cout_tiles = L.cout_tiles;
-  a.nchunks = L.Cin / C::CC;
+  a.nchunks = L.CinPad / C::CC;
   const int grid = B * a.tiles_x * a.tiles_y * a.cout_tiles;
   hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), 0, s, a);
 }
 
-void launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s) {
+void launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
   switch (L.variant) {
-    case CONV3_ROW32_RELU: launch_cfg<CfgRow32Relu>(L, in, out, B, s); break;
-    case CONV3_ROW32_RELU_POOL: launch_cfg<CfgRow32ReluPool>(L, in, out, B, s); break;
-    case CONV3_BLK16_RELU: launch_cfg<CfgBlk16Relu>(L, in, out, B, s); break;
-    case CONV1_BLK16_LINEAR: launch_cfg<CfgConv1Blk16>(L, in, out, B, s); break;
+    case CONV3_ROW32_RELU: launch_cfg<CfgRow32Relu>(L, io, B, s); break;
+    case CONV3_ROW32_RELU_POOL: launch_cfg<CfgRow32ReluPool>(L, io, B, s); break;
+    case CONV3_BLK16_RELU: launch_cfg<CfgBlk16Relu>(L, io, B, s); break;
+    case CONV1_BLK16_LINEAR: launch_cfg<CfgConv1Blk16>(L, io, B, s); break;
+    case CONV6S2_ROW32_SILU: launch_cfg<CfgStem6Row32>(L, io, B, s); break;
+    case CONV3S2_ROW32_SILU: launch_cfg<CfgS2Row32Silu>(L, io, B, s); break;
+    case CONV3S2_BLK16_SILU: launch_cfg<CfgS2Blk16Silu>(L, io, B, s); break;
+    case CONV3_ROW32_SILU: launch_cfg<CfgRow32Silu>(L, io, B, s); break;
+    case CONV3_BLK16_SILU: launch_cfg<CfgBlk16Silu>(L, io, B, s); break;
+    case CONV1_ROW32_SILU: launch_cfg<CfgConv1Row32Silu>(L, io, B, s); break;
+    case CONV1_BLK16_SILU: launch_cfg<CfgConv1Blk16Silu>(L, io, B, s); break;
   }
+}
+
+// SuperPoint convenience form: whole tensors in the standard padded planar layout
+void launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s) {
+  ConvIO io;
+  io.in = in.p; io.out = out.p; io.res = nullptr;
+  io.H = in.H; io.W = in.W;   // stride-1 layers: conv output dims == input dims (pooling happens in the epilogue)
+  io.iHp = in.Hp; io.iWp = in.Wp; io.ipady = in.pady; io.oHp = out.Hp; io.oWp = out.Wp; io.opady = out.pady;
+  io.in_fs = in.frame_stride(); io.out_fs = out.frame_stride(); io.res_fs = 0;
+  launch_conv_io(L, io, B, s);
 }
 
 const char* conv_kernel_name(ConvVariant v) {
   switch (v) {
-    case CONV3_ROW32_RELU: return "conv_mfma_kernel<Cfg<3,1,32,2,8,true,false>>";
-    case CONV3_ROW32_RELU_POOL: return "conv_mfma_kernel<Cfg<3,1,32,2,8,true,true>>";
-    case CONV3_BLK16_RELU: return "conv_mfma_kernel<Cfg<3,2,16,2,8,true,false>>";
-    case CONV1_BLK16_LINEAR: return "conv_mfma_kernel<Cfg<1,2,16,2,32,false,false>>";
+    case CONV3_ROW32_RELU: return "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,false>>";
+    case CONV3_ROW32_RELU_POOL: return "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,true>>";
+    case CONV3_BLK16_RELU: return "conv_mfma_kernel<Cfg<3,1,2,16,2,8,RELU,false>>";
+    case CONV1_BLK16_LINEAR: return "conv_mfma_kernel<Cfg<1,1,2,16,2,32,NONE,false>>";
+    default: return "conv_mfma_kernel<yolo variant>";
   }
-  return "?";
 }
 
 // OIHW -> [cout_tile][chunk][cp][tap][cc][NCO]; couts beyond Cout are zero rows.
 void pack_conv_weights(const float* w, const float* bias, int Cin, int Cout, int ks, int CC, int NCO, float* wp,
                        float* bp) {
-  const int T = ks * ks, cout_tiles = (Cout + NCO - 1) / NCO, nch = Cin / CC;
+  const int T = ks * ks, cout_tiles = (Cout + NCO - 1) / NCO, nch = (Cin + CC - 1) / CC;   // Cin padded up to CC
   size_t o = 0;
   for (int ct = 0; ct < cout_tiles; ct++)
     for (int ch = 0; ch < nch; ch++)
@@ -232,7 +272,7 @@ void pack_conv_weights(const float* w, const float* bias, int Cin, int Cout, int
           for (int cc = 0; cc < 2; cc++)
             for (int co = 0; co < NCO; co++) {
               const int cout = ct * NCO + co, cin = ch * CC + 2 * cp + cc;
-              wp[o++] = (cout < Cout) ? w[((size_t)cout * Cin + cin) * T + t] : 0.0f;
+              wp[o++] = (cout < Cout && cin < Cin) ? w[((size_t)cout * Cin + cin) * T + t] : 0.0f;
             }
   for (int i = 0; i < cout_tiles * NCO; i++) bp[i] = (i < Cout) ? bias[i] : 0.0f;
 }

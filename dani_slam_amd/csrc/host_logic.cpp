@@ -226,3 +226,117 @@ void distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY
 }
 
 }  // namespace dani
+
+// =================================================================================================
+// YOLO host stages: order-defining greedy NMS and integer box bookkeeping (reference keeps them on the host too).
+// =================================================================================================
+#include <cstring>
+#include <map>
+#include <string>
+
+namespace dani {
+
+// cand8 records: {bitcast pred index, cx, cy, w, h, obj, max class prob, bitcast class}.  Restates
+// non_max_suppression (/root/reference/src/YoloDetect.cpp:84-146) after its score filter: xywh -> xyxy in place,
+// score = obj * max class, descending sort, repeat {keep first; keep only boxes with IoU <= thresh}.
+// A NaN IoU (degenerate boxes) fails `<=` and is dropped, as `ious <= iou_thresh` does in the reference.
+int yolo_nms_host(const float* cand8, int n, float iou_thresh, float* dets6, int cap) {
+  struct Det { int idx; float x1, y1, x2, y2, score, cls, area; };
+  std::vector<Det> d(n);
+  for (int i = 0; i < n; i++) {
+    const float* c = cand8 + (size_t)i * 8;
+    int idx, cls;
+    memcpy(&idx, &c[0], 4); memcpy(&cls, &c[7], 4);
+    Det& o = d[i];
+    o.idx = idx;
+    o.x1 = c[1] - c[3] / 2.0f; o.y1 = c[2] - c[4] / 2.0f;
+    o.x2 = o.x1 + c[3]; o.y2 = o.y1 + c[4];
+    o.score = c[5] * c[6]; o.cls = (float)cls;
+    o.area = (o.y2 - o.y1) * (o.x2 - o.x1);
+  }
+  std::sort(d.begin(), d.end(), [](const Det& a, const Det& b) { return a.idx < b.idx; });   // prediction order
+  std::vector<int> order(n);
+  for (int i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a].score > d[b].score; });
+  int k = 0;
+  std::vector<int> rest;
+  while (!order.empty()) {
+    const Det& f = d[order[0]];
+    if (k < cap) { float* o = dets6 + (size_t)k * 6; o[0] = f.x1; o[1] = f.y1; o[2] = f.x2; o[3] = f.y2; o[4] = f.score; o[5] = f.cls; }
+    k++;
+    rest.clear();
+    for (size_t i = 1; i < order.size(); i++) {
+      const Det& g = d[order[i]];
+      const float left = std::max(f.x1, g.x1), top = std::max(f.y1, g.y1);
+      const float right = std::min(f.x2, g.x2), bottom = std::min(f.y2, g.y2);
+      const float w = std::max(0.0f, right - left), h = std::max(0.0f, bottom - top);
+      const float overlap = w * h;
+      const float iou = overlap / (f.area + g.area - overlap);
+      if (iou <= iou_thresh) rest.push_back(order[i]);
+    }
+    order.swap(rest);
+  }
+  return k;
+}
+
+namespace {
+struct IRect { int x, y, w, h; int area() const { return w * h; } };
+IRect rect_and(const IRect& a, const IRect& b) {   // cv::Rect operator&
+  const int x = std::max(a.x, b.x), y = std::max(a.y, b.y);
+  const int w = std::min(a.x + a.w, b.x + b.w) - x, h = std::min(a.y + a.h, b.y + b.h) - y;
+  if (w <= 0 || h <= 0) return IRect{0, 0, 0, 0};
+  return IRect{x, y, w, h};
+}
+}  // namespace
+
+int yolo_dynamic_areas(const float* dets6, int n, int cols, int rows, const char* const* class_names, int n_classes,
+                       const char* const* dynamic_names, int n_dynamic, int32_t* det_rects, int32_t* dyn_boxes, int cap) {
+  if (n <= 0) return 0;   // `if (dets.size() > 0)`: nothing is pushed, not even the placeholder
+  auto is_dynamic = [&](const std::string& nm) {
+    for (int i = 0; i < n_dynamic; i++) if (nm == dynamic_names[i]) return true;
+    return false;
+  };
+  std::map<std::string, std::vector<IRect>> detect_map;   // std::map: static classes are applied in name order
+  std::vector<IRect> dynamic;
+  for (int i = 0; i < n; i++) {
+    const float* d = dets6 + (size_t)i * 6;
+    const float left = d[0] * (float)cols / 640, top = d[1] * (float)rows / 384;     // quirk Q10: rows / 384
+    const float right = d[2] * (float)cols / 640, bottom = d[3] * (float)rows / 384;
+    const int cid = (int)d[5];
+    const IRect r{(int)left, (int)top, (int)(right - left), (int)(bottom - top)};     // float -> int truncation
+    if (det_rects) { det_rects[4 * i] = r.x; det_rects[4 * i + 1] = r.y; det_rects[4 * i + 2] = r.w; det_rects[4 * i + 3] = r.h; }
+    const std::string nm = (cid >= 0 && cid < n_classes) ? class_names[cid] : "";
+    detect_map[nm].push_back(r);
+    if (is_dynamic(nm)) dynamic.push_back(r);
+  }
+  if (dynamic.empty()) dynamic.push_back(IRect{1, 1, 1, 1});
+  int k = 0;
+  for (const IRect& D : dynamic) {
+    std::vector<IRect> sub{D}, nw;
+    for (const auto& kv : detect_map) {
+      if (is_dynamic(kv.first)) continue;
+      for (const IRect& S : kv.second) {
+        nw.clear();
+        for (const IRect& region : sub) {
+          const IRect in = rect_and(region, S);
+          if (in.area() > 0) {
+            if (in.y > region.y) nw.push_back(IRect{region.x, region.y, region.w, in.y - region.y});
+            if (in.y + in.h < region.y + region.h) nw.push_back(IRect{region.x, in.y + in.h, region.w, region.y + region.h - (in.y + in.h)});
+            if (in.x > region.x) nw.push_back(IRect{region.x, region.y, in.x - region.x, region.h});
+            if (in.x + in.w < region.x + region.w) nw.push_back(IRect{in.x + in.w, region.y, region.x + region.w - (in.x + in.w), region.h});
+          } else nw.push_back(region);
+        }
+        sub = nw;
+      }
+    }
+    if (!sub.empty()) {
+      IRect best = sub[0];
+      for (size_t i = 1; i < sub.size(); i++) if (best.area() < sub[i].area()) best = sub[i];
+      if (k < cap) { dyn_boxes[4 * k] = best.x; dyn_boxes[4 * k + 1] = best.y; dyn_boxes[4 * k + 2] = best.w; dyn_boxes[4 * k + 3] = best.h; }
+      k++;
+    }
+  }
+  return k;
+}
+
+}  // namespace dani

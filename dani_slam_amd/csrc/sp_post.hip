@@ -305,13 +305,13 @@ void launch_descriptors(const float* desc_nhwc, int Hc, int Wc, int PH, int PW, 
 }
 
 // tests only: padded planar frame b -> dense [C][H][W]
-__global__ void copy_dense_kernel(const float* a, int C, int H, int W, int Hp, int Wp, float* out) {
+__global__ void copy_dense_kernel(const float* a, int C, int H, int W, int Hp, int Wp, int pady, float* out) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
-  if (x < W) out[((size_t)c * H + y) * W + x] = a[((size_t)c * Hp + y + PADY) * Wp + x + PADX];
+  if (x < W) out[((size_t)c * H + y) * W + x] = a[((size_t)c * Hp + y + pady) * Wp + x + PADX];
 }
 void launch_copy_layer_dense(const ActDesc& a, int b, float* out_dense, hipStream_t s) {
   hipLaunchKernelGGL(copy_dense_kernel, dim3((a.W + 63) / 64, a.H, a.C), dim3(64), 0, s, a.p + b * a.frame_stride(),
-                     a.C, a.H, a.W, a.Hp, a.Wp, out_dense);
+                     a.C, a.H, a.W, a.Hp, a.Wp, a.pady, out_dense);
 }
 
 }  // namespace dani

@@ -77,6 +77,11 @@ def load_library():
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_lg_debug_fetch.argtypes = [C.c_void_p, C.c_int32, _f, _i32, _f, C.c_int32]
+    lib.dani_yolo_detect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_float, C.c_float, _f, C.c_int32, _i32]
+    lib.dani_host_dynamic_areas.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32,
+                                            C.POINTER(C.c_char_p), C.c_int32, _i32, _i32, C.c_int32]
+    lib.dani_yolo_debug_raw.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int64]
     lib.dani_host_distribute_octtree.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.c_int32, _i32, C.c_int32]
     lib.dani_host_cell_grid.argtypes = [C.c_int32, C.c_int32, _i32, C.c_int32]
@@ -120,6 +125,24 @@ def host_features_per_level(nfeatures, scaleFactor, nlevels):
     if rc:
         raise DaniError(rc, "dani_host_features_per_level")
     return per, sc
+
+
+def host_dynamic_areas(dets6, cols, rows, class_names, dynamic_names):
+    """Detect()'s box bookkeeping + RefineDynamicBoxes (src/YoloDetect.cpp:51-80,148-208).
+    Returns (dynamic boxes [k,4] int32, det rects [n,4] int32)."""
+    lib = load_library()
+    dets6 = np.ascontiguousarray(dets6, np.float32).reshape(-1, 6)
+    n = len(dets6)
+    cn = (C.c_char_p * len(class_names))(*[x.encode() for x in class_names])
+    dn = (C.c_char_p * len(dynamic_names))(*[x.encode() for x in dynamic_names])
+    rects = np.zeros((max(n, 1), 4), np.int32)
+    cap = max(n, 1) + 1
+    dyn = np.zeros((cap, 4), np.int32)
+    k = lib.dani_host_dynamic_areas(_fp(dets6), n, cols, rows, cn, len(class_names), dn, len(dynamic_names), _ip(rects),
+                                    _ip(dyn), cap)
+    if k < 0:
+        raise DaniError(k, "dani_host_dynamic_areas")
+    return dyn[:k].copy(), rects[:n].copy()
 
 
 # ---- engine -------------------------------------------------------------------------------------
@@ -256,6 +279,30 @@ class Engine:
         self._check(self.lib.dani_lg_debug_fetch(self.h, set_index, _fp(d), _ip(m0), _fp(mx), n))
         return d, m0, mx
 
+    # -- YOLO ------------------------------------------------------------------------------------
+    def yolo_detect_batch(self, bgr, score_thresh=0.4, iou_thresh=0.5, cap=2048, device_ptr=None, shape=None):
+        """bgr: uint8 [B, H, W, 3] host array (or device_ptr + shape=(B, H, W, stride)).  Returns a list of dets [k, 6]."""
+        if device_ptr is None:
+            bgr = np.ascontiguousarray(bgr, np.uint8)
+            if bgr.ndim == 3:
+                bgr = bgr[None]
+            B, H, W, _ = bgr.shape
+            stride = bgr.strides[1]
+            ptr, on_dev = bgr.ctypes.data_as(C.c_void_p), 0
+        else:
+            B, H, W, stride = shape
+            ptr, on_dev = C.c_void_p(device_ptr), 1
+        d = np.empty((B, cap, 6), np.float32); n = np.zeros(B, np.int32)
+        self._check(self.lib.dani_yolo_detect_batch(self.h, ptr, on_dev, B, W, H, stride, C.c_float(score_thresh),
+                                                    C.c_float(iou_thresh), _fp(d), cap, _ip(n)))
+        return [d[b, :n[b]].copy() for b in range(B)]
+
+    def yolo_debug_raw(self, b, level):
+        ny, nx = [(48, 80), (24, 40), (12, 20)][level]
+        out = np.empty((255, ny, nx), np.float32)
+        self._check(self.lib.dani_yolo_debug_raw(self.h, b, level, _fp(out), out.size))
+        return out
+
     def set_profiling(self, on=True):
         self._check(self.lib.dani_set_profiling(self.h, int(on)))
 
@@ -355,3 +402,42 @@ class LightGlue:
         s2 = None if size2 is None or len(size2) == 0 else size2
         m, s = self.engine.lg_match(xy(keypoints1), descriptors1, xy(keypoints2), descriptors2, s1, s2, threshold)
         return [DMatch(int(a), int(b), float(c)) for (a, b), c in zip(m, s)]
+
+
+COCO_NAMES_DEFAULT = None   # set by YoloDetection from `coco.names` (CWD, as the reference) or the ctor argument
+
+
+class YoloDetection:
+    """Mirror of ::YoloDetection (include/YoloDetect.h:16-41): GetImage / Detect / ClearImage / ClearArea and the
+    public result fields mvDynamicArea, mmDetectMap, mClassnames, mvDynamicNames."""
+
+    def __init__(self, engine: Engine | None = None, class_names=None):
+        self.engine = engine or default_engine()
+        if class_names is None:
+            if not os.path.exists("coco.names"):
+                raise FileNotFoundError("coco.names (read from the CWD, src/YoloDetect.cpp:12) not found")
+            class_names = [l.rstrip("\n") for l in open("coco.names")]
+        self.mClassnames = list(class_names)
+        self.mvDynamicNames = ["person", "car", "motorbike", "bus", "train", "truck", "boat", "bird", "cat",
+                               "dog", "horse", "sheep", "crow", "bear"]     # src/YoloDetect.cpp:17-18
+        self.mvDynamicArea = []
+        self.mmDetectMap = {}
+        self.mvPersonArea = []
+        self.mRGB = None
+
+    def GetImage(self, rgb): self.mRGB = rgb
+    def ClearImage(self): self.mRGB = None
+    def ClearArea(self): self.mvPersonArea = []
+
+    def Detect(self) -> bool:
+        if self.mRGB is None or np.asarray(self.mRGB).size == 0:
+            print("Read RGB failed!")
+            return False
+        img = np.asarray(self.mRGB)
+        dets = self.engine.yolo_detect_batch(img, 0.4, 0.5)[0]
+        if len(dets) > 0:
+            dyn, rects = host_dynamic_areas(dets, img.shape[1], img.shape[0], self.mClassnames, self.mvDynamicNames)
+            for d, r in zip(dets, rects):
+                self.mmDetectMap.setdefault(self.mClassnames[int(d[5])], []).append(tuple(int(v) for v in r))
+            self.mvDynamicArea = [tuple(int(v) for v in r) for r in dyn]
+        return True

@@ -146,3 +146,56 @@ def matching_pair(seed: int, n0: int = 1024, n1: int = 1024, overlap: float = 0.
     d0 = d0 / np.linalg.norm(d0, axis=0, keepdims=True)
     d1 = d1 / np.linalg.norm(d1, axis=0, keepdims=True)
     return k0, d0.astype(np.float32), k1, d1.astype(np.float32), gt
+
+
+# ---------------------------------------------------------------------------------------------------------
+# YOLOv5s: seeded synthetic weights under the public fused state_dict names (the reference's network is the absent
+# TorchScript blob yolov5s.torchscript.pt, /root/reference/src/YoloDetect.cpp:9).
+# ---------------------------------------------------------------------------------------------------------
+def _yolo_conv_list():
+    """(name, cin, cout, k) for every convolution of YOLOv5s v6 (width 0.5, depth 0.33), BN folded."""
+    L = []
+
+    def conv(name, cin, cout, k):
+        L.append((name + ".conv", cin, cout, k))
+
+    def c3(name, c1, c2, n):
+        c_ = c2 // 2
+        conv(f"{name}.cv1", c1, c_, 1); conv(f"{name}.cv2", c1, c_, 1); conv(f"{name}.cv3", 2 * c_, c2, 1)
+        for j in range(n):
+            conv(f"{name}.m.{j}.cv1", c_, c_, 1); conv(f"{name}.m.{j}.cv2", c_, c_, 3)
+
+    conv("model.0", 3, 32, 6); conv("model.1", 32, 64, 3); c3("model.2", 64, 64, 1)
+    conv("model.3", 64, 128, 3); c3("model.4", 128, 128, 2)
+    conv("model.5", 128, 256, 3); c3("model.6", 256, 256, 3)
+    conv("model.7", 256, 512, 3); c3("model.8", 512, 512, 1)
+    conv("model.9.cv1", 512, 256, 1); conv("model.9.cv2", 1024, 512, 1)
+    conv("model.10", 512, 256, 1); c3("model.13", 512, 256, 1)
+    conv("model.14", 256, 128, 1); c3("model.17", 256, 128, 1)
+    conv("model.18", 128, 128, 3); c3("model.20", 256, 256, 1)
+    conv("model.21", 256, 256, 3); c3("model.23", 512, 512, 1)
+    return L
+
+
+YOLO_CONVS = _yolo_conv_list()
+YOLO_DETECT_CH = (128, 256, 512)
+
+
+def yolo_weights(seed: int = 0, obj_bias: float = -2.0, head_gain: float = 1.0, gain: float = 1.5) -> dict:
+    """Variance-preserving random convolutions (SiLU gain) and a Detect head whose objectness logits are biased so
+    that a synthetic frame yields tens of candidates above the reference's 0.4 score threshold (gain 1.5 sits at the
+    edge where the SiLU stack neither dies out nor blows up for this seed)."""
+    rng = np.random.RandomState(2000 + seed)
+    w = {}
+    for name, cin, cout, k in YOLO_CONVS:
+        fan_in = cin * k * k
+        bound = np.sqrt(3.0) * gain / np.sqrt(fan_in)
+        w[name + ".weight"] = rng.uniform(-bound, bound, size=(cout, cin, k, k)).astype(np.float32)
+        w[name + ".bias"] = rng.uniform(-0.1, 0.1, size=(cout,)).astype(np.float32)
+    for i, ch in enumerate(YOLO_DETECT_CH):
+        bound = np.sqrt(3.0) * head_gain / np.sqrt(ch)
+        w[f"model.24.m.{i}.weight"] = rng.uniform(-bound, bound, size=(255, ch, 1, 1)).astype(np.float32)
+        b = rng.uniform(-0.2, 0.2, size=(3, 85)).astype(np.float32)
+        b[:, 4] += np.float32(obj_bias)
+        w[f"model.24.m.{i}.bias"] = b.reshape(-1)
+    return w

@@ -161,6 +161,33 @@ DANI_API int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int3
  * call on this thread, as [n][256] f32, and the raw row results (best column and log-score per query row). */
 DANI_API int dani_lg_debug_fetch(dani_engine* e, int32_t set, float* desc_out, int32_t* m0, float* max0, int32_t cap);
 
+/* ---- YOLO dynamic-object detector ---------------------------------------------------------- */
+
+/* Replaces the GPU-worthy part of YoloDetection::Detect (src/YoloDetect.cpp:27-82): resize to 640x380 +
+ * BGR->RGB + /255 (:39-46), the YOLOv5s forward (:49, absent TorchScript blob -> public v6 architecture) and
+ * non_max_suppression (:84-146, score_thresh 0.4 / iou_thresh 0.5 at the call site :50).
+ *   bgr/stride : 8-bit BGR image (cv::Mat mRGB), `stride` bytes per row
+ *   dets6      : cap x 6 (x1, y1, x2, y2, score, class) in the network's 640x380 input coordinates, in the
+ *                reference's keep order;  *n_out : count
+ * Weight tensors: public fused YOLOv5s names (model.0.conv.weight/.bias ... model.24.m.2.weight/.bias). */
+DANI_API int dani_yolo_detect(dani_engine* e, const uint8_t* bgr, int32_t width, int32_t height, int32_t stride,
+                              float score_thresh, float iou_thresh, float* dets6, int32_t cap, int32_t* n_out);
+/* Batched: B images of identical size, host or (imgs_on_device != 0) device pointer; outputs B slabs of cap. */
+DANI_API int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t imgs_on_device, int32_t B, int32_t width,
+                                    int32_t height, int32_t stride, float score_thresh, float iou_thresh, float* dets6,
+                                    int32_t cap, int32_t* n_out);
+/* The rest of Detect() (:51-80) + RefineDynamicBoxes (:148-208), pure host integer logic: boxes rescaled by
+ * cols/640 and rows/384 (quirk Q10), truncated to int rects, split by class name into static / dynamic
+ * (mvDynamicNames), placeholder (1,1,1,1) when detections exist but none is dynamic, static-box subtraction in
+ * std::map (class-name) order.  det_rects: n x 4 (may be NULL); dyn_boxes: cap x 4 = mvDynamicArea.
+ * Returns the number of dynamic boxes (or a negative status). */
+DANI_API int dani_host_dynamic_areas(const float* dets6, int32_t n, int32_t cols, int32_t rows,
+                                     const char* const* class_names, int32_t n_classes,
+                                     const char* const* dynamic_names, int32_t n_dynamic, int32_t* det_rects,
+                                     int32_t* dyn_boxes, int32_t cap);
+/* Test hook: raw Detect-layer output [255][ny][nx] of level 0..2 for frame b of the last YOLO call. */
+DANI_API int dani_yolo_debug_raw(dani_engine* e, int32_t b, int32_t level, float* out, int64_t count);
+
 /* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
 
 /* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.

@@ -188,3 +188,41 @@ def sp_extract(img, weights, nfeatures=1024, scaleFactor=1.2, nlevels=1, iniTh=0
     if want_maps:
         r["prob"] = prob; r["desc_map"] = dmap
     return r
+
+
+# ---- general conv / pooling / resize used by oracle/yolo_oracle.py ---------------------------------------
+def conv2d_ex(x, w, b, stride, pad, act):
+    """act: 0 none, 1 ReLU, 2 SiLU.  x [Cin,H,W], w [Cout,Cin,k,k]."""
+    x = np.ascontiguousarray(x, np.float32); w = np.ascontiguousarray(w, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    cin, h, wd = x.shape
+    cout, cin2, k, _ = w.shape
+    assert cin == cin2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    out = np.empty((cout, ho, wo), np.float32)
+    rc = lib().orc_conv2d_ex(_fp(x), cin, h, wd, _fp(w), _fp(b), cout, k, stride, pad, act, _fp(out))
+    assert rc == 0
+    return out
+
+
+def maxpool5(x):
+    x = np.ascontiguousarray(x, np.float32)
+    c, h, w = x.shape
+    out = np.empty_like(x)
+    lib().orc_maxpool5(_fp(x), c, h, w, _fp(out))
+    return out
+
+
+def resize_bilinear_u8c3(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    sh, sw, _ = img.shape
+    out = np.empty((dh, dw, 3), np.uint8)
+    lib().orc_resize_bilinear_u8c3(img.ctypes.data_as(_u8), sw, sh, img.strides[0], out.ctypes.data_as(_u8), dw, dh)
+    return out
+
+
+def sigmoid(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().orc_sigmoid(_fp(x), _fp(out), C.c_long(x.size))
+    return out

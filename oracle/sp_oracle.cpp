@@ -609,3 +609,108 @@ ORC_API int orc_sp_extract(const uint8_t* img, int W, int H, int stride, const f
   if (mono_index) *mono_index = monoIndex;
   return n;
 }
+
+// ============================================================================
+// General convolution for the YOLOv5s restatement (oracle/yolo_oracle.py): any k, stride, padding, canonical
+// chain order (cp, ky, kx, cc) from acc = bias, activation 0 none / 1 ReLU / 2 SiLU.
+// SiLU canonical form: x / (1 + dani_expf(-x)).
+// ============================================================================
+ORC_API int orc_conv2d_ex(const float* in, int Cin, int H, int W, const float* w, const float* b, int Cout, int k,
+                          int stride, int pad, int act, float* out) {
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad + stride * 8;
+  std::vector<float> xp((size_t)Cin * Hp * Wp, 0.0f);
+  for (int c = 0; c < Cin; c++)
+    for (int y = 0; y < H; y++)
+      memcpy(&xp[((size_t)c * Hp + y + pad) * Wp + pad], &in[((size_t)c * H + y) * W], sizeof(float) * W);
+  const int ncp = (Cin + 1) / 2;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int co = 0; co < Cout; co++) {
+    std::vector<float> acc(Wo);
+    for (int y = 0; y < Ho; y++) {
+      for (int x = 0; x < Wo; x++) acc[x] = b ? b[co] : 0.0f;
+      for (int cp = 0; cp < ncp; cp++)
+        for (int ky = 0; ky < k; ky++)
+          for (int kx = 0; kx < k; kx++)
+            for (int cc = 0; cc < 2; cc++) {
+              const int c = 2 * cp + cc;
+              if (c >= Cin) continue;
+              const float wv = w[(((size_t)co * Cin + c) * k + ky) * k + kx];
+              const float* src = &xp[((size_t)c * Hp + y * stride + ky) * Wp + kx];
+              if (stride == 1) {
+#pragma omp simd
+                for (int x = 0; x < Wo; x++) acc[x] = __builtin_fmaf(src[x], wv, acc[x]);
+              } else {
+                for (int x = 0; x < Wo; x++) acc[x] = __builtin_fmaf(src[x * stride], wv, acc[x]);
+              }
+            }
+      float* dst = &out[((size_t)co * Ho + y) * Wo];
+      for (int x = 0; x < Wo; x++) {
+        float v = acc[x];
+        if (act == 1) v = v > 0.0f ? v : 0.0f;
+        else if (act == 2) v = v / (1.0f + dani_expf(-v));
+        dst[x] = v;
+      }
+    }
+  }
+  return 0;
+}
+
+// nn.MaxPool2d(kernel 5, stride 1, padding 2) (implicit -inf padding), SPPF.
+ORC_API void orc_maxpool5(const float* in, int C, int H, int W, float* out) {
+  for (int c = 0; c < C; c++)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        float m = -INFINITY;
+        for (int dy = -2; dy <= 2; dy++)
+          for (int dx = -2; dx <= 2; dx++) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) m = fmaxf(m, in[((size_t)c * H + yy) * W + xx]);
+          }
+        out[((size_t)c * H + y) * W + x] = m;
+      }
+}
+
+// cv::resize(src, dst, Size(dw, dh)) with INTER_LINEAR on 8UC3, restated from OpenCV's fixed-point path
+// (INTER_RESIZE_COEF_BITS = 11: horizontal pass into int32 with coefficients scaled by 2048, vertical pass
+//  dst = ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  Used by YoloDetection::Detect,
+// /root/reference/src/YoloDetect.cpp:39.  (OpenCV itself is absent from this image; YOLO parity is box-level.)
+ORC_API void orc_resize_bilinear_u8c3(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh) {
+  const double sx = (double)sw / dw, sy = (double)sh / dh;
+  std::vector<int> xofs(dw), yofs(dh);
+  std::vector<short> xa(2 * dw), ya(2 * dh);
+  auto coefs = [](int d, double scale, int ssize, int& ofs, short* ab) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= s;
+    if (s < 0) { s = 0; f = 0; }
+    if (s >= ssize - 1) { s = ssize - 1; f = (s == ssize - 1 && ssize >= 1) ? 0.f : f; if (s > ssize - 1) s = ssize - 1; }
+    ofs = s;
+    ab[0] = (short)lrintf((1.f - f) * 2048.f);
+    ab[1] = (short)lrintf(f * 2048.f);
+  };
+  for (int x = 0; x < dw; x++) coefs(x, sx, sw, xofs[x], &xa[2 * x]);
+  for (int y = 0; y < dh; y++) coefs(y, sy, sh, yofs[y], &ya[2 * y]);
+  std::vector<int> r0((size_t)dw * 3), r1((size_t)dw * 3);
+  auto hrow = [&](int srow, std::vector<int>& o) {
+    srow = std::min(std::max(srow, 0), sh - 1);
+    const uint8_t* S = src + (size_t)srow * sstride;
+    for (int x = 0; x < dw; x++) {
+      const int s0 = xofs[x], s1 = std::min(s0 + 1, sw - 1);
+      for (int c = 0; c < 3; c++) o[3 * x + c] = S[3 * s0 + c] * xa[2 * x] + S[3 * s1 + c] * xa[2 * x + 1];
+    }
+  };
+  for (int y = 0; y < dh; y++) {
+    hrow(yofs[y], r0); hrow(yofs[y] + 1, r1);
+    const int b0 = ya[2 * y], b1 = ya[2 * y + 1];
+    for (int i = 0; i < dw * 3; i++) {
+      const int v = (((b0 * (r0[i] >> 4)) >> 16) + ((b1 * (r1[i] >> 4)) >> 16) + 2) >> 2;
+      dst[(size_t)y * dw * 3 + i] = (uint8_t)std::min(std::max(v, 0), 255);
+    }
+  }
+}
+
+// canonical sigmoid 1 / (1 + dani_expf(-x)) (Detect layer), elementwise
+ORC_API void orc_sigmoid(const float* in, float* out, long n) {
+  for (long i = 0; i < n; i++) out[i] = 1.0f / (1.0f + dani_expf(-in[i]));
+}
