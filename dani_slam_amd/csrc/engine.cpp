@@ -56,6 +56,9 @@ struct Context {
   int box_cap = 0;
   uint8_t* d_img = nullptr;
   size_t d_img_bytes = 0;
+  float* d_kxy_all = nullptr;
+  float* d_desc_all = nullptr;
+  int prev_n = 0;            // keypoints of the cached previous frame (slot 0)
   float* d_kxy = nullptr;
   int32_t* d_nk = nullptr;
   float* d_sampled = nullptr;
@@ -111,14 +114,18 @@ int fail(dani_engine* e, int code, const char* fmt, ...) {
   } while (0)
 
 thread_local Context* t_last_ctx = nullptr;
+thread_local Context* t_borrowed = nullptr;     // set by dani_frontend_batch: nested ABI calls reuse its context
+thread_local bool t_keep_desc_on_device = false;
 
 Context* acquire(dani_engine* e) {
+  if (t_borrowed) return t_borrowed;
   std::lock_guard<std::mutex> lk(e->mu);
   for (Context* c : e->ctxs)
     if (!c->busy) { c->busy = true; return c; }
   return nullptr;
 }
 void release(dani_engine* e, Context* c) {
+  if (c == t_borrowed) return;
   std::lock_guard<std::mutex> lk(e->mu);
   c->busy = false;
 }
@@ -183,10 +190,15 @@ int ensure_shapes(dani_engine* e, Context* c, int W, int H, int B, int kcap) {
   c->d_img_bytes = (size_t)B * H * round_up(W, 64) * 2;
   if ((rc = dev_alloc(e, c, (void**)&c->d_img, c->d_img_bytes, false))) return rc;
   c->kcap = kcap;
-  if ((rc = dev_alloc(e, c, (void**)&c->d_kxy, ((size_t)B * kcap * 2 + B) * 4, false))) return rc;
+  // feature slabs: slot 0 holds the last frame of the previous dani_frontend_batch call (sequence matching),
+  // slots 1..B the current frames; d_kxy / d_descout point at slot 1
+  if ((rc = dev_alloc(e, c, (void**)&c->d_kxy_all, ((size_t)(B + 1) * kcap * 2 + B) * 4, true))) return rc;
+  c->d_kxy = c->d_kxy_all + (size_t)kcap * 2;
   c->d_nk = reinterpret_cast<int32_t*>(c->d_kxy + (size_t)B * kcap * 2);
   if ((rc = dev_alloc(e, c, (void**)&c->d_sampled, ((size_t)B * kcap * 256 + B * 256) * 4, false))) return rc;
-  if ((rc = dev_alloc(e, c, (void**)&c->d_descout, (size_t)B * kcap * 256 * 4, false))) return rc;
+  if ((rc = dev_alloc(e, c, (void**)&c->d_desc_all, (size_t)(B + 1) * kcap * 256 * 4, true))) return rc;
+  c->d_descout = c->d_desc_all + (size_t)kcap * 256;
+  c->prev_n = 0;
   if ((rc = host_alloc(e, c, (void**)&c->h_cand, (size_t)B * CAND_CAP * 3 * 4))) return rc;
   if ((rc = host_alloc(e, c, (void**)&c->h_cand_count, (size_t)B * 4))) return rc;
   if ((rc = host_alloc(e, c, (void**)&c->h_kxy, ((size_t)B * kcap * 2 + B) * 4))) return rc;
@@ -353,7 +365,7 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   if (!imgs || W <= 0 || H <= 0) return fail(e, DANI_ERR_EMPTY, "empty image");
   if (!e->finalized) return fail(e, DANI_ERR_WEIGHTS, "weights not finalized (call dani_finalize_weights)");
   if (B < 1 || B > e->cfg.max_batch) return fail(e, DANI_ERR_INVALID, "batch %d outside [1, %d]", B, e->cfg.max_batch);
-  if (stride < W || cap < 1 || !n_out || !kpts_xy || !resp || !desc) return fail(e, DANI_ERR_INVALID, "bad argument");
+  if (stride < W || cap < 1 || !n_out || !kpts_xy || !resp || (!desc && !t_keep_desc_on_device)) return fail(e, DANI_ERR_INVALID, "bad argument");
   int rc = check_params(e, W, H, p);
   if (rc) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
@@ -461,7 +473,7 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   launch_descriptors(c->desc_nhwc, Hc, Wc, PH, PW, c->d_kxy, c->d_nk, B, c->kcap, c->d_sampled, c->d_descout, s);
   HIP_TRY(e, hipEventRecord(c->ev[4], s));
   for (int b = 0; b < B; b++)
-    if (n_out[b])
+    if (n_out[b] && desc)
       HIP_TRY(e, hipMemcpyAsync(desc + (size_t)b * cap * 256, c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));
   HIP_TRY(e, hipGetLastError());
@@ -1219,6 +1231,146 @@ int dani_yolo_debug_raw(dani_engine* e, int32_t b, int32_t level, float* out, in
   if (st == hipSuccess) st = hipStreamSynchronize(c->stream);
   (void)hipFree(tmp);
   if (st != hipSuccess) return fail(e, DANI_ERR_HIP, "debug copy failed");
+  return DANI_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// Fused per-frame front-end (sequence mode)
+// ================================================================================================
+namespace {
+
+struct SeqState {
+  std::mutex mu;
+  Context* ctx = nullptr;
+  std::vector<std::string> class_names, dynamic_names;
+  float ms[4] = {0, 0, 0, 0};
+};
+std::map<dani_engine*, SeqState*> g_seq;
+std::mutex g_seq_mu;
+
+SeqState* seq_state(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(g_seq_mu);
+  auto it = g_seq.find(e);
+  if (it != g_seq.end()) return it->second;
+  SeqState* s = new SeqState();
+  g_seq[e] = s;
+  return s;
+}
+thread_local SeqState* t_last_seq = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+int dani_yolo_set_classes(dani_engine* e, const char* const* class_names, int32_t n_classes,
+                          const char* const* dynamic_names, int32_t n_dynamic) {
+  if (!e || !class_names || !dynamic_names || n_classes < 1 || n_dynamic < 0) return fail(e, DANI_ERR_INVALID, "bad class list");
+  SeqState* S = seq_state(e);
+  std::lock_guard<std::mutex> lk(S->mu);
+  S->class_names.assign(class_names, class_names + n_classes);
+  S->dynamic_names.assign(dynamic_names, dynamic_names + n_dynamic);
+  return DANI_OK;
+}
+
+int dani_frontend_reset(dani_engine* e) {
+  if (!e) return DANI_ERR_INVALID;
+  SeqState* S = seq_state(e);
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (S->ctx) S->ctx->prev_n = 0;
+  return DANI_OK;
+}
+
+int dani_frontend_timings(dani_engine* e, float* ms4) {
+  if (!e || !ms4 || !t_last_seq) return DANI_ERR_INVALID;
+  for (int i = 0; i < 4; i++) ms4[i] = t_last_seq->ms[i];
+  return DANI_OK;
+}
+
+int dani_frontend_batch(dani_engine* e, const uint8_t* gray, int32_t gray_stride, const uint8_t* bgr, int32_t bgr_stride,
+                        int32_t on_device, int32_t B, int32_t W, int32_t H, const dani_frontend_params* p, float* kpts_xy,
+                        float* resp, float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index, int32_t* dyn_boxes,
+                        int32_t box_cap, int32_t* n_boxes, int32_t* matches, float* scores, int32_t match_cap,
+                        int32_t* k_out) {
+  if (!e || !p) return DANI_ERR_INVALID;
+  if (!gray || W <= 0 || H <= 0) return fail(e, DANI_ERR_EMPTY, "empty image");
+  if (B < 1 || B > e->cfg.max_batch) return fail(e, DANI_ERR_INVALID, "batch %d outside [1, %d]", B, e->cfg.max_batch);
+  if (p->use_yolo && (!bgr || !dyn_boxes || !n_boxes || box_cap < 1)) return fail(e, DANI_ERR_INVALID, "use_yolo needs bgr + box outputs");
+  if (p->match_previous && (!matches || !scores || !k_out || match_cap < 1)) return fail(e, DANI_ERR_INVALID, "match_previous needs match outputs");
+  SeqState* S = seq_state(e);
+  std::lock_guard<std::mutex> seq_lock(S->mu);
+  if (p->use_yolo && S->class_names.empty()) return fail(e, DANI_ERR_INVALID, "call dani_yolo_set_classes first (coco.names)");
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (!S->ctx) {
+    Context* c = new Context();
+    HIP_TRY(e, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    for (auto& ev : c->lev) (void)hipEventCreate(&ev);
+    c->busy = true;   // never handed out by acquire()
+    { std::lock_guard<std::mutex> lk(e->mu); e->ctxs.push_back(c); }
+    S->ctx = c;
+  }
+  Context* c = S->ctx;
+  struct Borrow { Borrow(Context* c) { t_borrowed = c; } ~Borrow() { t_borrowed = nullptr; t_keep_desc_on_device = false; } } borrow(c);
+  t_last_seq = S;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+
+  // ---- 1. YOLO -> dynamic boxes (Tracking.cc:1535-1539)
+  std::vector<int32_t> boxes, offs(B + 1, 0);
+  if (p->use_yolo) {
+    const int dcap = 4096;
+    std::vector<float> dets((size_t)B * dcap * 6);
+    std::vector<int32_t> nd(B);
+    int rc = dani_yolo_detect_batch(e, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
+    if (rc) return rc;
+    std::vector<const char*> cn, dn;
+    for (auto& s : S->class_names) cn.push_back(s.c_str());
+    for (auto& s : S->dynamic_names) dn.push_back(s.c_str());
+    std::vector<int32_t> tmp((size_t)(dcap + 1) * 4);
+    for (int b = 0; b < B; b++) {
+      const int k = yolo_dynamic_areas(dets.data() + (size_t)b * dcap * 6, nd[b], W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp.data(), dcap + 1);
+      n_boxes[b] = k;
+      if (k > box_cap) return fail(e, DANI_ERR_CAPACITY, "frame %d has %d dynamic boxes (> %d)", b, k, box_cap);
+      memcpy(dyn_boxes + (size_t)b * box_cap * 4, tmp.data(), (size_t)k * 16);
+      boxes.insert(boxes.end(), tmp.begin(), tmp.begin() + (size_t)k * 4);
+      offs[b + 1] = offs[b] + k;
+    }
+  } else if (n_boxes) {
+    for (int b = 0; b < B; b++) n_boxes[b] = 0;
+  }
+  S->ms[0] = ms_since(t0);
+
+  // ---- 2. SuperPoint with the boxes as mvDynamicArea; descriptors stay resident for LightGlue
+  const auto t1 = std::chrono::steady_clock::now();
+  t_keep_desc_on_device = true;
+  std::vector<int32_t> octave((size_t)B * cap);
+  std::vector<float> size((size_t)B * cap);
+  int rc = dani_sp_extract_batch(e, gray, on_device, B, W, H, gray_stride, &p->sp, boxes.empty() ? nullptr : boxes.data(),
+                                 boxes.empty() ? nullptr : offs.data(), p->lapping, kpts_xy, resp, octave.data(), size.data(),
+                                 desc, cap, n_out, mono_index);
+  t_keep_desc_on_device = false;
+  if (rc) return rc;
+  S->ms[1] = ms_since(t1);
+
+  // ---- 3. LightGlue: frame b-1 (query) vs frame b (train); slot 0 of the feature slabs = previous call's last frame
+  const auto t2 = std::chrono::steady_clock::now();
+  if (p->match_previous) {
+    std::vector<int32_t> n0(B), n1(B);
+    for (int b = 0; b < B; b++) { n0[b] = b ? n_out[b - 1] : c->prev_n; n1[b] = n_out[b]; }
+    const float sz[2] = {(float)W, (float)H};
+    rc = dani_lg_match_batch(e, B, c->kcap, 1, c->d_kxy_all, c->d_desc_all, n0.data(), c->d_kxy, c->d_descout, n1.data(), sz, sz,
+                             p->lg_threshold, matches, scores, match_cap, k_out);
+    if (rc) return rc;
+  }
+  // cache the last frame's features as the next call's predecessor
+  HIP_TRY(e, hipMemcpyAsync(c->d_kxy_all, c->d_kxy + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(e, hipStreamSynchronize(c->stream));
+  c->prev_n = n_out[B - 1];
+  S->ms[2] = ms_since(t2);
+  S->ms[3] = ms_since(t0);
   return DANI_OK;
 }
 

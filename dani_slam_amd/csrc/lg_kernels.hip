@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const float* Q, const floa
   __shared__ float sV[64 * AT_STRIDE];
   const LgSet st = sets[blockIdx.z];
   const int q0 = blockIdx.x * 128;
-  if (q0 >= st.n) return;
+  if (q0 >= ((st.n + 31) & ~31)) return;
   const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
   const int k_off = cross ? st.partner_off : st.tok_off, k_n = cross ? st.partner_n : st.n;
@@ -324,13 +324,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const float* Q, const floa
   }
 #undef AT_PREFETCH
   const float lt = l + __shfl_xor(l, 32);
-  const float inv = 1.0f / lt;
-  if (qi < st.n) {
+  const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;            // empty key set -> zero message
+  // padding queries (n <= qi < padded n) get zeros so that every column of the set stays finite: masked keys are
+  // multiplied by p = 0 in later layers, and 0 * NaN would poison valid rows
+  if (qi < ((st.n + 31) & ~31)) {
+    const float keep = qi < st.n ? inv : 0.0f;
     float* Oh = O + (size_t)head * 64 * ld + st.tok_off + qi;
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) Oh[(size_t)(db * 32 + acc_row(r, h)) * ld] = o[db][r] * inv;
+      for (int r = 0; r < 16; r++) Oh[(size_t)(db * 32 + acc_row(r, h)) * ld] = qi < st.n ? o[db][r] * keep : 0.0f;
   }
 }
 

@@ -40,10 +40,18 @@ class _Config(C.Structure):
                 ("max_height", C.c_int32), ("n_contexts", C.c_int32)]
 
 
+class _FrontendParams(C.Structure):
+    pass
+
+
 class _SpParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("ini_th", C.c_float), ("min_th", C.c_float)]
 
+
+_FrontendParams._fields_ = [("sp", _SpParams), ("use_yolo", C.c_int32), ("yolo_score_thresh", C.c_float),
+                            ("yolo_iou_thresh", C.c_float), ("match_previous", C.c_int32), ("lg_threshold", C.c_float),
+                            ("lapping", C.c_int32 * 2)]
 
 _lib = None
 
@@ -82,6 +90,12 @@ def load_library():
     lib.dani_host_dynamic_areas.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.c_int32,
                                             C.POINTER(C.c_char_p), C.c_int32, _i32, _i32, C.c_int32]
     lib.dani_yolo_debug_raw.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int64]
+    lib.dani_yolo_set_classes.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_char_p), C.c_int32]
+    lib.dani_frontend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.POINTER(_FrontendParams), _f, _f, _f, C.c_int32, _i32, _i32,
+                                        _i32, C.c_int32, _i32, _i32, _f, C.c_int32, _i32]
+    lib.dani_frontend_reset.argtypes = [C.c_void_p]
+    lib.dani_frontend_timings.argtypes = [C.c_void_p, _f]
     lib.dani_host_distribute_octtree.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.c_int32, _i32, C.c_int32]
     lib.dani_host_cell_grid.argtypes = [C.c_int32, C.c_int32, _i32, C.c_int32]
@@ -302,6 +316,69 @@ class Engine:
         out = np.empty((255, ny, nx), np.float32)
         self._check(self.lib.dani_yolo_debug_raw(self.h, b, level, _fp(out), out.size))
         return out
+
+    # -- fused front-end (sequence mode) ------------------------------------------------------------
+    def yolo_set_classes(self, class_names, dynamic_names):
+        cn = (C.c_char_p * len(class_names))(*[x.encode() for x in class_names])
+        dn = (C.c_char_p * len(dynamic_names))(*[x.encode() for x in dynamic_names])
+        self._check(self.lib.dani_yolo_set_classes(self.h, cn, len(class_names), dn, len(dynamic_names)))
+
+    def frontend_reset(self):
+        self._check(self.lib.dani_frontend_reset(self.h))
+
+    def frontend_batch(self, gray, bgr=None, nfeatures=1024, iniTh=0.015, minTh=0.007, use_yolo=True, match_previous=True,
+                       lg_threshold=0.05, lapping=(0, 0), want_desc=True, device_ptrs=None, shape=None, box_cap=512, copy=True):
+        """gray [B,H,W] u8 and bgr [B,H,W,3] u8 host arrays, or device_ptrs=(gray_ptr, bgr_ptr) + shape=(B,H,W).
+        Returns a list of per-frame dicts: kpts, resp, desc (or None), mono_index, boxes [k,4], matches [K,2], scores.
+        copy=False returns views into buffers that the next call overwrites."""
+        if device_ptrs is None:
+            gray = np.ascontiguousarray(gray, np.uint8)
+            B, H, W = gray.shape
+            gp, gs = gray.ctypes.data_as(C.c_void_p), gray.strides[1]
+            if use_yolo:
+                bgr = np.ascontiguousarray(bgr, np.uint8)
+                bp, bs = bgr.ctypes.data_as(C.c_void_p), bgr.strides[1]
+            else:
+                bp, bs = None, 0
+            on_dev = 0
+        else:
+            B, H, W = shape
+            gp, gs = C.c_void_p(device_ptrs[0]), W
+            bp, bs = (C.c_void_p(device_ptrs[1]), 3 * W) if use_yolo else (None, 0)
+            on_dev = 1
+        cap = nfeatures + 8
+        p = _FrontendParams()
+        p.sp = _SpParams(nfeatures, 1.2, 1, iniTh, minTh)
+        p.use_yolo = int(use_yolo); p.yolo_score_thresh = 0.4; p.yolo_iou_thresh = 0.5
+        p.match_previous = int(match_previous); p.lg_threshold = lg_threshold
+        p.lapping[0], p.lapping[1] = int(lapping[0]), int(lapping[1])
+        bufs = getattr(self, "_fe_bufs", None)
+        key = (B, cap, box_cap, want_desc)
+        if bufs is None or bufs[0] != key:
+            bufs = (key, dict(k=np.empty((B, cap, 2), np.float32), r=np.empty((B, cap), np.float32),
+                              d=np.empty((B, cap, 256), np.float32) if want_desc else None,
+                              n=np.zeros(B, np.int32), mono=np.zeros(B, np.int32),
+                              boxes=np.zeros((B, box_cap, 4), np.int32), nb=np.zeros(B, np.int32),
+                              m=np.zeros((B, cap, 2), np.int32), sc=np.zeros((B, cap), np.float32), ko=np.zeros(B, np.int32)))
+            self._fe_bufs = bufs
+        o = bufs[1]
+        rc = self.lib.dani_frontend_batch(self.h, gp, gs, bp, bs, on_dev, B, W, H, C.byref(p), _fp(o["k"]), _fp(o["r"]),
+                                          _fp(o["d"]) if want_desc else None, cap, _ip(o["n"]), _ip(o["mono"]),
+                                          _ip(o["boxes"]), box_cap, _ip(o["nb"]), _ip(o["m"]), _fp(o["sc"]), cap, _ip(o["ko"]))
+        self._check(rc)
+        res = []
+        for b in range(B):
+            n, nb, k = int(o["n"][b]), int(o["nb"][b]), int(o["ko"][b]) if match_previous else 0
+            res.append(dict(kpts=o["k"][b, :n], resp=o["r"][b, :n], desc=o["d"][b, :n] if want_desc else None,
+                            mono_index=int(o["mono"][b]), boxes=o["boxes"][b, :nb], matches=o["m"][b, :k], scores=o["sc"][b, :k]))
+        if copy:
+            res = [{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for r in res]
+        return res
+
+    def frontend_timings(self):
+        ms = np.zeros(4, np.float32)
+        self._check(self.lib.dani_frontend_timings(self.h, _fp(ms)))
+        return ms
 
     def set_profiling(self, on=True):
         self._check(self.lib.dani_set_profiling(self.h, int(on)))

@@ -188,6 +188,43 @@ DANI_API int dani_host_dynamic_areas(const float* dets6, int32_t n, int32_t cols
 /* Test hook: raw Detect-layer output [255][ny][nx] of level 0..2 for frame b of the last YOLO call. */
 DANI_API int dani_yolo_debug_raw(dani_engine* e, int32_t b, int32_t level, float* out, int64_t count);
 
+/* ---- fused per-frame front-end (sequence mode) ---------------------------------------------- */
+
+/* The class list the reference reads from `coco.names` in the CWD (src/YoloDetect.cpp:12-16) and its dynamic class
+ * names (mvDynamicNames, :17-18); needed by dani_frontend_batch to turn detections into mvDynamicArea. */
+DANI_API int dani_yolo_set_classes(dani_engine* e, const char* const* class_names, int32_t n_classes,
+                                   const char* const* dynamic_names, int32_t n_dynamic);
+
+typedef struct dani_frontend_params {
+  dani_sp_params sp;
+  int32_t use_yolo;        /* 1: RGB-D path (Tracking::GrabImageRGBD, src/Tracking.cc:1534-1545): YOLO boxes cull SuperPoint */
+  float yolo_score_thresh; /* 0.4 at the reference's call site (src/YoloDetect.cpp:50) */
+  float yolo_iou_thresh;   /* 0.5 */
+  int32_t match_previous;  /* 1: LightGlue-match every frame against its predecessor in the sequence */
+  float lg_threshold;      /* 0.05 (include/LightGlue.h:23) */
+  int32_t lapping[2];      /* vLappingArea */
+} dani_frontend_params;
+
+/* One call = the whole per-frame front-end of the reference for B consecutive frames of ONE sequence, chained on the
+ * device: YoloDetection::Detect -> mvDynamicArea hand-off (src/Tracking.cc:1535-1539) -> SPextractor::operator()
+ * -> LightGlue::matchDescriptors(previous frame, this frame).  Frame 0 of the call is matched against the last
+ * frame of the previous call (features stay resident in HBM); the very first frame has no predecessor (k_out = 0).
+ *   gray : B x height x gray_stride u8 (what Tracking passes to the Frame constructor after cvtColor)
+ *   bgr  : B x height x bgr_stride u8, 3 channels (what Tracking passes to YoloDetection::GetImage); NULL if !use_yolo
+ *   imgs_on_device : both image pointers are device pointers (frames already resident in HBM)
+ * Outputs (host): keypoints / responses / descriptors as dani_sp_extract_batch (desc may be NULL: descriptors then
+ * stay on the device only), dyn_boxes [B][box_cap][4] + n_boxes [B] (= mvDynamicArea per frame),
+ * matches [B][match_cap][2] = (index in previous frame, index in this frame), scores, k_out [B]. */
+DANI_API int dani_frontend_batch(dani_engine* e, const uint8_t* gray, int32_t gray_stride, const uint8_t* bgr,
+                                 int32_t bgr_stride, int32_t imgs_on_device, int32_t B, int32_t width, int32_t height,
+                                 const dani_frontend_params* p, float* kpts_xy, float* resp, float* desc, int32_t cap,
+                                 int32_t* n_out, int32_t* mono_index, int32_t* dyn_boxes, int32_t box_cap,
+                                 int32_t* n_boxes, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out);
+/* Forget the cached previous frame (start of a new sequence). */
+DANI_API int dani_frontend_reset(dani_engine* e);
+/* Stage wall times (ms) of the last dani_frontend_batch on this thread: [0] yolo, [1] superpoint, [2] lightglue, [3] total. */
+DANI_API int dani_frontend_timings(dani_engine* e, float* ms4);
+
 /* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
 
 /* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.

@@ -1,0 +1,56 @@
+"""GPU: the fused per-frame front-end (YOLO boxes -> SuperPoint cull -> LightGlue vs previous frame) against the
+composition of the three oracles on the same synthetic sequence."""
+import numpy as np
+import pytest
+
+from dani_slam_amd import synth
+from oracle import lg_oracle as lg
+from oracle import oracle
+from oracle import yolo_oracle as yo
+
+pytestmark = pytest.mark.gpu
+NF = 300
+
+
+@pytest.fixture(scope="module")
+def weights(sp_weights):
+    w = dict(sp_weights); w.update(synth.lightglue_weights(0)); w.update(synth.yolo_weights(0))
+    return w
+
+
+def test_sequence_matches_oracle_composition(weights, sp_weights):
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=2, weights=weights)
+    e.yolo_set_classes(yo.COCO_NAMES, yo.DYNAMIC_NAMES)
+    frames = [0, 1, 2, 3]
+    gray = np.stack([synth.frame(i) for i in frames]); bgr = np.stack([synth.frame_bgr(i) for i in frames])
+    # two calls of two frames: frame 2 must be matched against frame 1 (cached from the previous call)
+    out = e.frontend_batch(gray[:2], bgr[:2], nfeatures=NF) + e.frontend_batch(gray[2:], bgr[2:], nfeatures=NF)
+    out = [{k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in o.items()} for o in out]
+    prev = None
+    for i, f in enumerate(frames):
+        ok, dets, dyn, dmap = yo.detect(weights, bgr[i])
+        assert [tuple(int(v) for v in r) for r in out[i]["boxes"]] == [tuple(r) for r in dyn]
+        ref = oracle.sp_extract(gray[i], sp_weights, nfeatures=NF, boxes=dyn)
+        assert np.array_equal(out[i]["kpts"], ref["kpts"])
+        assert np.array_equal(out[i]["desc"], ref["desc"])
+        if prev is None:
+            assert len(out[i]["matches"]) == 0
+        else:
+            mo, so = lg.match_descriptors(weights, prev["kpts"], prev["desc"], ref["kpts"], ref["desc"], (640, 480), (640, 480), 0.05)
+            a = {tuple(x) for x in mo.tolist()}; b = {tuple(x) for x in out[i]["matches"].tolist()}
+            assert len(a ^ b) <= max(2, len(a) // 50), (len(a), len(b), len(a ^ b))     # near-tie flips only
+            sd = {tuple(x): v for x, v in zip(out[i]["matches"].tolist(), out[i]["scores"])}
+            for x, v in zip(mo.tolist(), so):
+                if tuple(x) in sd:
+                    assert abs(sd[tuple(x)] - v) < 1e-3
+        prev = ref
+    # reset forgets the predecessor
+    e.frontend_reset()
+    o2 = e.frontend_batch(gray[:1], bgr[:1], nfeatures=NF)
+    assert len(o2[0]["matches"]) == 0
+    # without YOLO (stereo path) nothing is culled
+    o3 = e.frontend_batch(gray[:1], None, nfeatures=NF, use_yolo=False, match_previous=False)
+    ref = oracle.sp_extract(gray[0], sp_weights, nfeatures=NF)
+    assert np.array_equal(o3[0]["kpts"], ref["kpts"])
+    e.close()
