@@ -2,10 +2,10 @@
 """bench.py -- front-end throughput on MI355X (BASELINE.json metric: frames/sec at 640x480).
 
 A "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
-FRAMES_PER_GPU (8 = BASELINE config #4's 64 frames / 8 GPUs) 640x480 frames per GPU through
-dani_sp_extract_batch (SuperPoint extraction, 1024 keypoints; the LightGlue and YOLO stages are added to the
-step as they land -- `config.workload` always says what was timed).  Frames are batch-sharded over ranks with
-no data-path collective (weak scaling).
+FRAMES_PER_GPU (8 = BASELINE config #4's 64 frames / 8 GPUs) 640x480 frames per GPU through dani_frontend_batch,
+i.e. the full front-end of BASELINE config #4: YOLOv5s dynamic-object boxes -> SuperPoint extraction (1024
+keypoints, boxes culled) -> LightGlue match of every frame against its predecessor.  Frames are batch-sharded over
+ranks with no data-path collective (weak scaling).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -45,24 +45,30 @@ def exact_layer_flops(li, B):
     return 2.0 * h * w * cout * cin * k * k * B
 
 
-def cpu_baseline(frames):
-    """Time the oracle (CPU port of the reference path) on a bounded sample: whole-frame extraction."""
-    from dani_slam_amd import synth
-    from oracle import oracle
+def cpu_baseline(gray, bgr, weights):
+    """Time the oracles (CPU port of the reference's LibTorch-CPU path) on a bounded sample of the same frames:
+    YOLO detect -> SuperPoint extract with the boxes -> LightGlue vs the previous frame."""
+    from oracle import lg_oracle, oracle, yolo_oracle
     cores = len(os.sched_getaffinity(0))
-    w = synth.superpoint_weights(0)
     oracle.lib()
     n = 0
+    prev = None
     t0 = time.perf_counter()
     while True:
-        oracle.sp_extract(frames[n % len(frames)], w, nfeatures=NFEATURES)
+        i = n % len(gray)
+        ok, dets, dyn, dmap = yolo_oracle.detect(weights, bgr[i])
+        cur = oracle.sp_extract(gray[i], weights, nfeatures=NFEATURES, boxes=dyn)
+        if prev is not None:
+            lg_oracle.match_descriptors(weights, prev["kpts"], prev["desc"], cur["kpts"], cur["desc"], (W, H), (W, H), 0.05)
+        prev = cur
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 12.0 or n >= 24:
+        if dt > 20.0 or n >= 8:
             break
     return {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 640x480 frames through oracle.sp_extract (CPU restatement of "
-                      f"SPextractor::operator(), OpenMP over {cores} cores), {dt:.1f} s"}
+            "sample": f"{n} synthetic 640x480 frames through the oracle composition yolo_oracle.detect -> "
+                      f"oracle.sp_extract -> lg_oracle.match_descriptors ({n - 1} pairs) on {cores} host cores "
+                      f"(OpenMP C for the convolutions, numpy/BLAS for LightGlue), {dt:.1f} s"}
 
 
 def main():
@@ -71,6 +77,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequences", type=int, default=2,
+                    help="independent image sequences (cameras) processed concurrently per GPU, one host thread each; "
+                         "steps are dealt round-robin to them")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,33 +101,58 @@ def main():
 
     B = FRAMES_PER_GPU
     # this rank's shard of the synthetic sequence: frames rank*B .. rank*B+B-1
+    from oracle import yolo_oracle as _names   # class-name lists only (coco.names is not shipped by the reference)
     frames = np.stack([synth.frame(rank * B + i) for i in range(B)])
+    frames_bgr = np.stack([synth.frame_bgr(rank * B + i) for i in range(B)])
     d_frames = torch.from_numpy(frames).to(dev)          # inputs resident in HBM before the timed region
-    eng = frontend.Engine(device=local_rank, max_batch=B, max_width=W, max_height=H,
-                          weights=synth.superpoint_weights(0))
+    d_bgr = torch.from_numpy(frames_bgr).to(dev)
+    weights = dict(synth.superpoint_weights(0)); weights.update(synth.lightglue_weights(0)); weights.update(synth.yolo_weights(0))
+    eng = frontend.Engine(device=local_rank, max_batch=B, max_width=W, max_height=H, weights=weights)
+    eng.yolo_set_classes(_names.COCO_NAMES, _names.DYNAMIC_NAMES)
 
-    def step():
-        return eng.sp_extract_batch(None, nfeatures=NFEATURES, device_ptr=d_frames.data_ptr(), shape=(B, H, W, W))
+    import threading
+    NSEQ = max(1, args.sequences)
+
+    def step(seq=0):
+        return eng.frontend_batch(None, None, nfeatures=NFEATURES, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()),
+                                  shape=(B, H, W), want_desc=True, copy=False, sequence=seq)
+
+    def run_steps(total, collect):
+        """`total` steps dealt round-robin to NSEQ concurrent sequences (one host thread each)."""
+        outs = [None] * NSEQ
+        acc = [(np.zeros(12), np.zeros(4)) for _ in range(NSEQ)]
+        errs = []
+
+        def worker(seq):
+            try:
+                for _ in range(total // NSEQ + (1 if seq < total % NSEQ else 0)):
+                    outs[seq] = step(seq)
+                    if collect:
+                        acc[seq][0][:] += eng.layer_timings()
+                        acc[seq][1][:] += eng.frontend_timings()
+            except Exception as ex:   # surface worker failures in the main thread
+                errs.append(ex)
+        th = [threading.Thread(target=worker, args=(q,)) for q in range(NSEQ)]
+        for t_ in th: t_.start()
+        for t_ in th: t_.join()
+        if errs:
+            raise errs[0]
+        return outs, sum(a[0] for a in acc), sum(a[1] for a in acc)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
+    run_steps(max(args.warmup, NSEQ), False)
     eng.set_profiling(True)
-    layer_ms = np.zeros(12)
-    stage_ms = np.zeros(5)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        layer_ms += eng.layer_timings()
-        stage_ms += eng.last_timings()
+    outs, layer_ms, fe_ms = run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     eng.set_profiling(False)
+    out = next(o for o in outs if o is not None)
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -130,7 +164,7 @@ def main():
         total_frames = B * world * args.steps
         fps = total_frames / dt_max
         layer_ms /= args.steps
-        stage_ms /= args.steps
+        fe_ms /= args.steps
         dom_ms = float(sum(layer_ms[i] for i in DOMINANT_LAYERS))
         dom_flops = sum(exact_layer_flops(i, B) for i in DOMINANT_LAYERS)
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -141,17 +175,21 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        conv_ms = float(stage_ms[0])
+        conv_ms = float(layer_ms.sum())
+        nmatch = [len(o["matches"]) for o in out]
+        nbox = [len(o["boxes"]) for o in out]
         res = {
             "metric": "frames/sec SuperPoint+LightGlue+YOLO front-end, 640x480, 1/2/4/8 MI355X",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SuperPoint extract stage of the front-end (BASELINE configs #2/#4): "
-                                   f"{B} synthetic 640x480 frames per GPU per step resident in HBM, nFeatures=1024, "
-                                   "nLevels=1, iniTh=0.015, minTh=0.007, seeded synthetic weights; LightGlue/YOLO "
-                                   "stages not yet in the step",
-                       "frames_per_gpu_per_step": B, "keypoints_per_frame": nk[:4],
+            "config": {"workload": "full front-end (BASELINE config #4 sharded): YOLOv5s boxes -> SuperPoint extract -> "
+                                   f"LightGlue vs previous frame, {B} synthetic 640x480 frames per GPU per step resident "
+                                   "in HBM, nFeatures=1024, nLevels=1, iniTh=0.015, minTh=0.007, LightGlue 9 layers "
+                                   "no early exit, seeded synthetic weights",
+                       "frames_per_gpu_per_step": B, "keypoints_per_frame": nk[:4], "matches_per_frame": nmatch[:4],
+                       "dynamic_boxes_per_frame": nbox[:4],
+                       "concurrent_sequences_per_gpu": NSEQ,
                        "parallelism": f"frame-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": DOMINANT_KERNEL, "achieved": round(achieved, 3),
                          "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -159,13 +197,14 @@ def main():
                          "launches_per_step": len(DOMINANT_LAYERS),
                          "avg_launch_ms": round(dom_ms / len(DOMINANT_LAYERS), 4),
                          "algorithmic_gflop_per_step": round(dom_flops / 1e9, 2)},
-            "stages_ms_per_step": {"conv_stack": round(conv_ms, 3), "softmax_norm_cells": round(float(stage_ms[1]), 3),
-                                   "host_quadtree": round(float(stage_ms[2]), 3), "descriptors": round(float(stage_ms[3]), 3)},
-            "conv_stack_tflops": round(SP_GFLOP_PER_FRAME * B / conv_ms, 2) if conv_ms > 0 else None,
+            "stages_ms_per_step": {"yolo": round(float(fe_ms[0]), 3), "superpoint": round(float(fe_ms[1]), 3),
+                                   "lightglue": round(float(fe_ms[2]), 3), "total": round(float(fe_ms[3]), 3),
+                                   "sp_conv_stack_device": round(conv_ms, 3)},
+            "sp_conv_stack_tflops": round(SP_GFLOP_PER_FRAME * B / conv_ms, 2) if conv_ms > 0 else None,
             "layer_ms": [round(float(x), 4) for x in layer_ms],
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(frames[:4])
+            res["cpu_baseline"] = cpu_baseline(frames[:4], frames_bgr[:4], weights)
         print(json.dumps(res), flush=True)
     eng.close()
     if world > 1:

@@ -15,6 +15,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -39,6 +40,8 @@ constexpr int CAND_CAP = 32768;  // candidates per frame kept on the device (ref
 
 struct Context {
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // YOLO (concurrent with the SuperPoint conv stack) and overlapped D2H copies
+  hipEvent_t ev_desc = nullptr, ev_y0 = nullptr, ev_y1 = nullptr;
   int W = 0, H = 0, B = 0;  // shapes the buffers are built for
   ActDesc act[12];          // output of layer i (layers 1,3,5: pooled)
   float* prob = nullptr;
@@ -116,6 +119,9 @@ int fail(dani_engine* e, int code, const char* fmt, ...) {
 thread_local Context* t_last_ctx = nullptr;
 thread_local Context* t_borrowed = nullptr;     // set by dani_frontend_batch: nested ABI calls reuse its context
 thread_local bool t_keep_desc_on_device = false;
+thread_local int t_sp_phase = 0;          // 0: whole extractor; 1: enqueue the network only; 2: everything after it
+thread_local bool t_alt_stream = false;   // YOLO on the context's second stream
+thread_local bool t_defer_desc_sync = false;  // fused call: descriptor D2H runs on stream2 under LightGlue
 
 Context* acquire(dani_engine* e) {
   if (t_borrowed) return t_borrowed;
@@ -251,7 +257,9 @@ int dani_engine_create(const dani_config* cfg, dani_engine** out) {
   if (hipSetDevice(e->device) != hipSuccess) { delete e; return fail(nullptr, DANI_ERR_HIP, "hipSetDevice failed"); }
   for (int i = 0; i < e->cfg.n_contexts; i++) {
     Context* c = new Context();
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
+    (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     for (auto& ev : c->lev) (void)hipEventCreate(&ev);
     e->ctxs.push_back(c);
@@ -269,6 +277,7 @@ void dani_engine_destroy(dani_engine* e) {
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->lev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
   }
   for (void* p : e->weight_allocs) (void)hipFree(p);
@@ -382,6 +391,9 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   const int Hc = H / 8, Wc = W / 8, PH = Hc * 8, PW = Wc * 8;
   const int ncells = (int)c->cells.size();
 
+  const bool prof = e->profiling;
+  const int phase = t_sp_phase;
+  if (phase != 2) {
   // ---- inputs
   const uint8_t* dimg = imgs;
   const size_t fbytes = (size_t)H * stride;
@@ -389,6 +401,22 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
     if (fbytes * B > c->d_img_bytes) return fail(e, DANI_ERR_INVALID, "stride %d too large for the staging buffer", stride);
     HIP_TRY(e, hipMemcpyAsync(c->d_img, imgs, fbytes * B, hipMemcpyHostToDevice, s));
     dimg = c->d_img;
+  }
+  // ---- network
+  HIP_TRY(e, hipEventRecord(c->ev[0], s));
+  if (prof) HIP_TRY(e, hipEventRecord(c->lev[0], s));
+  launch_conv1a(dimg, B, H, W, stride, fbytes, e->w1a, e->b1a, c->act[0], s);
+  if (prof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
+  const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
+  for (int i = 1; i < 12; i++) {
+    launch_conv_mfma(e->plan[i], c->act[src_of[i]], c->act[i], B, s);
+    if (prof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
+  }
+  HIP_TRY(e, hipEventRecord(c->ev[1], s));
+  launch_softmax_d2s(c->act[9], c->prob, B, s);
+  launch_desc_norm(c->act[11], c->desc_nhwc, c->desc_nchw, B, s);
+  HIP_TRY(e, hipGetLastError());
+  if (phase == 1) return DANI_OK;   // network enqueued; the caller continues with phase 2 once the boxes are known
   }
   int nboxes_total = 0;
   if (boxes && box_offsets) nboxes_total = box_offsets[B];
@@ -402,20 +430,6 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
     HIP_TRY(e, hipMemcpyAsync(c->d_box_offsets, ho, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
   }
 
-  // ---- network
-  const bool prof = e->profiling;
-  HIP_TRY(e, hipEventRecord(c->ev[0], s));
-  if (prof) HIP_TRY(e, hipEventRecord(c->lev[0], s));
-  launch_conv1a(dimg, B, H, W, stride, fbytes, e->w1a, e->b1a, c->act[0], s);
-  if (prof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
-  const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
-  for (int i = 1; i < 12; i++) {
-    launch_conv_mfma(e->plan[i], c->act[src_of[i]], c->act[i], B, s);
-    if (prof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
-  }
-  HIP_TRY(e, hipEventRecord(c->ev[1], s));
-  launch_softmax_d2s(c->act[9], c->prob, B, s);
-  launch_desc_norm(c->act[11], c->desc_nhwc, c->desc_nchw, B, s);
   if (ncells > 0) {
     launch_cell_nms(c->prob, PH, PW, B, c->d_cells, ncells, p->ini_th, p->min_th, c->d_boxes, c->d_box_offsets,
                     19 - 3, c->slot_xyr, c->slot_count, c->slot_stride, s);
@@ -438,12 +452,22 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   const int minBorderX = 19 - 3, minBorderY = minBorderX, maxBorderX = W - 19 + 3, maxBorderY = H - 19 + 3;
   const int scaledPatchSize = (int)(31 * scales[0]);
   int32_t* h_nk = reinterpret_cast<int32_t*>(c->h_kxy + (size_t)e->cfg.max_batch * c->kcap * 2);
-  std::vector<int> sel;
   int status = DANI_OK;
+  // the quadtree of each frame is independent: one host thread per frame (it is ~90 us of serial work per frame)
+  std::vector<std::vector<int>> sels(B);
+  {
+    auto work = [&](int b) {
+      const HostKey* keys = reinterpret_cast<const HostKey*>(c->h_cand + (size_t)b * CAND_CAP * 3);
+      distribute_octtree(keys, c->h_cand_count[b], minBorderX, maxBorderX, minBorderY, maxBorderY, N, sels[b]);
+    };
+    std::vector<std::thread> th;
+    for (int b = 1; b < B; b++) th.emplace_back(work, b);
+    work(0);
+    for (auto& t : th) t.join();
+  }
   for (int b = 0; b < B; b++) {
     const HostKey* keys = reinterpret_cast<const HostKey*>(c->h_cand + (size_t)b * CAND_CAP * 3);
-    const int nc = c->h_cand_count[b];
-    distribute_octtree(keys, nc, minBorderX, maxBorderX, minBorderY, maxBorderY, N, sel);
+    const std::vector<int>& sel = sels[b];
     const int n = (int)sel.size();
     n_out[b] = n;
     if (n > cap || n > c->kcap) { status = DANI_ERR_CAPACITY; h_nk[b] = 0; continue; }
@@ -472,9 +496,14 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   HIP_TRY(e, hipEventRecord(c->ev[3], s));
   launch_descriptors(c->desc_nhwc, Hc, Wc, PH, PW, c->d_kxy, c->d_nk, B, c->kcap, c->d_sampled, c->d_descout, s);
   HIP_TRY(e, hipEventRecord(c->ev[4], s));
-  for (int b = 0; b < B; b++)
-    if (n_out[b] && desc)
-      HIP_TRY(e, hipMemcpyAsync(desc + (size_t)b * cap * 256, c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, s));
+  if (desc) {   // descriptor read-back on the second stream so that it can run under the next stage's kernels
+    HIP_TRY(e, hipEventRecord(c->ev_desc, s));
+    HIP_TRY(e, hipStreamWaitEvent(c->stream2, c->ev_desc, 0));
+    for (int b = 0; b < B; b++)
+      if (n_out[b])
+        HIP_TRY(e, hipMemcpyAsync(desc + (size_t)b * cap * 256, c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, c->stream2));
+    if (!t_defer_desc_sync) HIP_TRY(e, hipStreamSynchronize(c->stream2));
+  }
   HIP_TRY(e, hipStreamSynchronize(s));
   HIP_TRY(e, hipGetLastError());
   (void)hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]);
@@ -575,7 +604,7 @@ int dani_host_features_per_level(int32_t nfeatures, float scale_factor, int32_t 
 // ================================================================================================
 namespace {
 
-constexpr int LG_LAYERS = 9, LG_DIM = 256;
+constexpr int LG_LAYERS = 9;
 
 struct LgLinear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
 struct LgBlockW { LgLinear a, b, c, ffn0, ffn3; float* ln_g = nullptr; float* ln_b = nullptr; };  // self: a=Wqkv,b=out_proj; cross: a=to_qk,b=to_v,c=to_out
@@ -624,13 +653,30 @@ int lg_upload(dani_engine* e, const std::vector<float>& v, float** out) {
   return 0;
 }
 
-// pack a torch Linear ([out, in] row-major) for linear_fm_kernel; `perm` optionally permutes output rows
-int lg_pack_linear(dani_engine* e, const std::string& name, int out, int in, LgLinear* L, const std::vector<int>* perm = nullptr) {
+// pack a Linear ([out, in] row-major + bias) for linear_fm_kernel
+int lg_pack_raw(dani_engine* e, const std::vector<float>& w, const std::vector<float>& b, int out, int in, LgLinear* L) {
+  const int tiles = (out + 63) / 64;
+  std::vector<float> wp((size_t)tiles * 64 * in), bp((size_t)tiles * 64);
+  pack_conv_weights(w.data(), b.data(), in, out, 1, 32, 64, wp.data(), bp.data());
+  L->out = out; L->in = in;
+  int rc;
+  if ((rc = lg_upload(e, wp, &L->w))) return rc;
+  return lg_upload(e, bp, &L->b);
+}
+
+int lg_get_linear(dani_engine* e, const std::string& name, int out, int in, std::vector<float>& w, std::vector<float>& b) {
   auto wi = e->tensors.find(name + ".weight"), bi = e->tensors.find(name + ".bias");
   if (wi == e->tensors.end() || bi == e->tensors.end()) return fail(e, DANI_ERR_WEIGHTS, "missing tensor %s.weight/.bias", name.c_str());
   if (wi->second.size() != (size_t)out * in || bi->second.size() != (size_t)out)
     return fail(e, DANI_ERR_WEIGHTS, "tensor %s.weight has %zu floats, expected [%d,%d]", name.c_str(), wi->second.size(), out, in);
-  std::vector<float> w(wi->second), b(bi->second);
+  w = wi->second; b = bi->second;
+  return 0;
+}
+
+int lg_pack_linear(dani_engine* e, const std::string& name, int out, int in, LgLinear* L, const std::vector<int>* perm = nullptr) {
+  std::vector<float> w, b;
+  int rc = lg_get_linear(e, name, out, in, w, b);
+  if (rc) return rc;
   if (perm) {
     std::vector<float> w2(w.size()), b2(b.size());
     for (int r = 0; r < out; r++) {
@@ -639,13 +685,45 @@ int lg_pack_linear(dani_engine* e, const std::string& name, int out, int in, LgL
     }
     w.swap(w2); b.swap(b2);
   }
-  const int tiles = (out + 63) / 64;
-  std::vector<float> wp((size_t)tiles * 64 * in), bp((size_t)tiles * 64);
-  pack_conv_weights(w.data(), b.data(), in, out, 1, 32, 64, wp.data(), bp.data());
-  L->out = out; L->in = in;
+  return lg_pack_raw(e, w, b, out, in, L);
+}
+
+// ffn.0 applied to cat[x, P(ctx)] with P an affine map (out_proj / to_out) folded in:
+//   W0 [x ; Wp ctx + bp] + b0 = [W0a | W0b Wp] [x ; ctx] + (b0 + W0b bp)        (products accumulated in double)
+// This removes one 256x256 GEMM launch per block (18 per forward) without changing the function computed.
+int lg_pack_ffn0_folded(dani_engine* e, const std::string& ffn0, const std::string& proj, LgLinear* L) {
+  std::vector<float> w0, b0, wp, bp;
   int rc;
-  if ((rc = lg_upload(e, wp, &L->w))) return rc;
-  return lg_upload(e, bp, &L->b);
+  if ((rc = lg_get_linear(e, ffn0, 512, 512, w0, b0))) return rc;
+  if ((rc = lg_get_linear(e, proj, 256, 256, wp, bp))) return rc;
+  std::vector<float> w(w0), b(b0);
+  for (int o = 0; o < 512; o++) {
+    const float* w0b = &w0[(size_t)o * 512 + 256];
+    for (int k = 0; k < 256; k++) {
+      double acc = 0.0;
+      for (int m = 0; m < 256; m++) acc += (double)w0b[m] * (double)wp[(size_t)m * 256 + k];
+      w[(size_t)o * 512 + 256 + k] = (float)acc;
+    }
+    double bb = (double)b0[o];
+    for (int m = 0; m < 256; m++) bb += (double)w0b[m] * (double)bp[m];
+    b[o] = (float)bb;
+  }
+  return lg_pack_raw(e, w, b, 512, 512, L);
+}
+
+// to_qk (pre-scaled by 64^-1/4, the factor the public CrossBlock applies to both sides) and to_v as one 512-row GEMM
+int lg_pack_qkv_cross(dani_engine* e, const std::string& pc, LgLinear* L) {
+  std::vector<float> wq, bq, wv, bv;
+  int rc;
+  if ((rc = lg_get_linear(e, pc + ".to_qk", 256, 256, wq, bq))) return rc;
+  if ((rc = lg_get_linear(e, pc + ".to_v", 256, 256, wv, bv))) return rc;
+  const float sc = 0.35355339059327373f;
+  std::vector<float> w((size_t)512 * 256), b(512);
+  for (size_t i = 0; i < wq.size(); i++) w[i] = wq[i] * sc;
+  for (int i = 0; i < 256; i++) b[i] = bq[i] * sc;
+  memcpy(&w[(size_t)256 * 256], wv.data(), wv.size() * 4);
+  memcpy(&b[256], bv.data(), 256 * 4);
+  return lg_pack_raw(e, w, b, 512, 256, L);
 }
 
 int lg_vec(dani_engine* e, const std::string& name, size_t n, float** out) {
@@ -669,15 +747,12 @@ int lg_finalize(dani_engine* e) {
     const std::string ps = "transformers." + std::to_string(i) + ".self_attn", pc = "transformers." + std::to_string(i) + ".cross_attn";
     LgBlockW& S = W->self_[i]; LgBlockW& C = W->cross_[i];
     if ((rc = lg_pack_linear(e, ps + ".Wqkv", 768, 256, &S.a, &perm))) return rc;
-    if ((rc = lg_pack_linear(e, ps + ".out_proj", 256, 256, &S.b))) return rc;
-    if ((rc = lg_pack_linear(e, ps + ".ffn.0", 512, 512, &S.ffn0))) return rc;
+    if ((rc = lg_pack_ffn0_folded(e, ps + ".ffn.0", ps + ".out_proj", &S.ffn0))) return rc;
     if ((rc = lg_vec(e, ps + ".ffn.1.weight", 512, &S.ln_g))) return rc;
     if ((rc = lg_vec(e, ps + ".ffn.1.bias", 512, &S.ln_b))) return rc;
     if ((rc = lg_pack_linear(e, ps + ".ffn.3", 256, 512, &S.ffn3))) return rc;
-    if ((rc = lg_pack_linear(e, pc + ".to_qk", 256, 256, &C.a))) return rc;
-    if ((rc = lg_pack_linear(e, pc + ".to_v", 256, 256, &C.b))) return rc;
-    if ((rc = lg_pack_linear(e, pc + ".to_out", 256, 256, &C.c))) return rc;
-    if ((rc = lg_pack_linear(e, pc + ".ffn.0", 512, 512, &C.ffn0))) return rc;
+    if ((rc = lg_pack_qkv_cross(e, pc, &C.a))) return rc;
+    if ((rc = lg_pack_ffn0_folded(e, pc + ".ffn.0", pc + ".to_out", &C.ffn0))) return rc;
     if ((rc = lg_vec(e, pc + ".ffn.1.weight", 512, &C.ln_g))) return rc;
     if ((rc = lg_vec(e, pc + ".ffn.1.bias", 512, &C.ln_b))) return rc;
     if ((rc = lg_pack_linear(e, pc + ".ffn.3", 256, 512, &C.ffn3))) return rc;
@@ -745,20 +820,18 @@ void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, h
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
     launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
   };
-  const float qk_scale = 0.35355339059327373f;  // (64^-0.5)^0.5 applied to both sides, as the public CrossBlock
   for (int i = 0; i < LG_LAYERS; i++) {
     const LgBlockW& S = W->self_[i]; const LgBlockW& C = W->cross_[i];
+    // self block: Wqkv (+rotary) -> attention -> [out_proj folded into] ffn.0 -> LN+GELU -> ffn.3 + residual
     lin(S.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 512, 1.0f);
     launch_attention(L->qkv, L->qkv + (size_t)256 * ld, L->qkv + (size_t)512 * ld, L->ctx, ld, L->d_sets, nsets, max_n, 0, 0.125f, s);
-    lin(S.b, L->ctx, 256, nullptr, 0, L->msg, nullptr, 0, 1.0f);
-    lin(S.ffn0, L->x, 256, L->msg, 256, L->hbuf, nullptr, 0, 1.0f);
+    lin(S.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
     launch_ln_gelu(L->hbuf, S.ln_g, S.ln_b, T, ld, s);
     lin(S.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
-    lin(C.a, L->x, 256, nullptr, 0, L->qk, nullptr, 0, qk_scale);
-    lin(C.b, L->x, 256, nullptr, 0, L->v, nullptr, 0, 1.0f);
-    launch_attention(L->qk, L->qk, L->v, L->ctx, ld, L->d_sets, nsets, max_n, 1, 1.0f, s);
-    lin(C.c, L->ctx, 256, nullptr, 0, L->msg, nullptr, 0, 1.0f);
-    lin(C.ffn0, L->x, 256, L->msg, 256, L->hbuf, nullptr, 0, 1.0f);
+    // cross block: [to_qk*s | to_v] in one GEMM -> attention over the partner set -> [to_out folded into] ffn.0 ...
+    lin(C.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 0, 1.0f);
+    launch_attention(L->qkv, L->qkv, L->qkv + (size_t)256 * ld, L->ctx, ld, L->d_sets, nsets, max_n, 1, 1.0f, s);
+    lin(C.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
     launch_ln_gelu(L->hbuf, C.ln_g, C.ln_b, T, ld, s);
     lin(C.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
   }
@@ -1171,16 +1244,16 @@ int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device
   int rc = yolo_ensure(e, c, &Y, e->cfg.max_batch, fbytes * e->cfg.max_batch);
   if (rc) return rc;
   t_last_yolo = Y; t_last_ctx = c;
-  hipStream_t s = c->stream;
+  hipStream_t s = t_alt_stream ? c->stream2 : c->stream;
   const uint8_t* dimg = bgr;
   if (!on_device) {
     HIP_TRY(e, hipMemcpyAsync(Y->d_img, bgr, fbytes * B, hipMemcpyHostToDevice, s));
     dimg = Y->d_img;
   }
-  HIP_TRY(e, hipEventRecord(c->ev[0], s));
+  HIP_TRY(e, hipEventRecord(c->ev_y0, s));
   launch_yolo_preproc(dimg, B, W, H, stride, fbytes, Y->buf.at("in"), s);
   yolo_forward(Wt, Y, B, score_thresh, s);
-  HIP_TRY(e, hipEventRecord(c->ev[1], s));
+  HIP_TRY(e, hipEventRecord(c->ev_y1, s));
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemcpyAsync(Y->h_count, Y->cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));
@@ -1190,8 +1263,7 @@ int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device
       HIP_TRY(e, hipMemcpyAsync(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->cand + (size_t)b * YOLO_CAND_CAP * 8, (size_t)Y->h_count[b] * 32, hipMemcpyDeviceToHost, s));
   }
   HIP_TRY(e, hipStreamSynchronize(s));
-  (void)hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]);
-  c->ms[4] = c->ms[0];
+  if (!t_alt_stream) { (void)hipEventElapsedTime(&c->ms[0], c->ev_y0, c->ev_y1); c->ms[4] = c->ms[0]; }
   int status = DANI_OK;
   for (int b = 0; b < B; b++) {
     const int k = yolo_nms_host(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->h_count[b], iou_thresh, dets6 + (size_t)b * cap * 6, cap);
@@ -1247,15 +1319,16 @@ struct SeqState {
   std::vector<std::string> class_names, dynamic_names;
   float ms[4] = {0, 0, 0, 0};
 };
-std::map<dani_engine*, SeqState*> g_seq;
+std::map<std::pair<dani_engine*, int>, SeqState*> g_seq;
 std::mutex g_seq_mu;
 
-SeqState* seq_state(dani_engine* e) {
+// one SeqState (context + cached previous frame) per (engine, sequence id); id 0 also holds the class lists
+SeqState* seq_state(dani_engine* e, int id = 0) {
   std::lock_guard<std::mutex> lk(g_seq_mu);
-  auto it = g_seq.find(e);
+  auto it = g_seq.find(std::make_pair(e, id));
   if (it != g_seq.end()) return it->second;
   SeqState* s = new SeqState();
-  g_seq[e] = s;
+  g_seq[std::make_pair(e, id)] = s;
   return s;
 }
 thread_local SeqState* t_last_seq = nullptr;
@@ -1274,9 +1347,9 @@ int dani_yolo_set_classes(dani_engine* e, const char* const* class_names, int32_
   return DANI_OK;
 }
 
-int dani_frontend_reset(dani_engine* e) {
+int dani_frontend_reset(dani_engine* e, int32_t sequence) {
   if (!e) return DANI_ERR_INVALID;
-  SeqState* S = seq_state(e);
+  SeqState* S = seq_state(e, sequence);
   std::lock_guard<std::mutex> lk(S->mu);
   if (S->ctx) S->ctx->prev_n = 0;
   return DANI_OK;
@@ -1288,7 +1361,7 @@ int dani_frontend_timings(dani_engine* e, float* ms4) {
   return DANI_OK;
 }
 
-int dani_frontend_batch(dani_engine* e, const uint8_t* gray, int32_t gray_stride, const uint8_t* bgr, int32_t bgr_stride,
+int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, int32_t gray_stride, const uint8_t* bgr, int32_t bgr_stride,
                         int32_t on_device, int32_t B, int32_t W, int32_t H, const dani_frontend_params* p, float* kpts_xy,
                         float* resp, float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index, int32_t* dyn_boxes,
                         int32_t box_cap, int32_t* n_boxes, int32_t* matches, float* scores, int32_t match_cap,
@@ -1298,13 +1371,21 @@ int dani_frontend_batch(dani_engine* e, const uint8_t* gray, int32_t gray_stride
   if (B < 1 || B > e->cfg.max_batch) return fail(e, DANI_ERR_INVALID, "batch %d outside [1, %d]", B, e->cfg.max_batch);
   if (p->use_yolo && (!bgr || !dyn_boxes || !n_boxes || box_cap < 1)) return fail(e, DANI_ERR_INVALID, "use_yolo needs bgr + box outputs");
   if (p->match_previous && (!matches || !scores || !k_out || match_cap < 1)) return fail(e, DANI_ERR_INVALID, "match_previous needs match outputs");
-  SeqState* S = seq_state(e);
+  SeqState* S0 = seq_state(e, 0);
+  SeqState* S = seq_state(e, sequence);
   std::lock_guard<std::mutex> seq_lock(S->mu);
-  if (p->use_yolo && S->class_names.empty()) return fail(e, DANI_ERR_INVALID, "call dani_yolo_set_classes first (coco.names)");
+  std::vector<std::string> class_names, dynamic_names;
+  if (p->use_yolo) {
+    if (S != S0) { std::lock_guard<std::mutex> lk0(S0->mu); class_names = S0->class_names; dynamic_names = S0->dynamic_names; }
+    else { class_names = S0->class_names; dynamic_names = S0->dynamic_names; }
+    if (class_names.empty()) return fail(e, DANI_ERR_INVALID, "call dani_yolo_set_classes first (coco.names)");
+  }
   HIP_TRY(e, hipSetDevice(e->device));
   if (!S->ctx) {
     Context* c = new Context();
     HIP_TRY(e, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(e, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     for (auto& ev : c->lev) (void)hipEventCreate(&ev);
     c->busy = true;   // never handed out by acquire()
@@ -1317,17 +1398,30 @@ int dani_frontend_batch(dani_engine* e, const uint8_t* gray, int32_t gray_stride
   const auto t0 = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
 
+  // ---- 0. enqueue the SuperPoint network first: it does not need the boxes, and running it on the main stream
+  //         while YOLO's ~70 small kernels run on the second stream fills the CUs those leave idle
+  std::vector<int32_t> octave((size_t)B * cap);
+  std::vector<float> size((size_t)B * cap);
+  t_keep_desc_on_device = true;
+  t_sp_phase = 1;
+  int rc = dani_sp_extract_batch(e, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
+                                 octave.data(), size.data(), desc, cap, n_out, mono_index);
+  t_sp_phase = 0;
+  if (rc) { t_keep_desc_on_device = false; return rc; }
+
   // ---- 1. YOLO -> dynamic boxes (Tracking.cc:1535-1539)
   std::vector<int32_t> boxes, offs(B + 1, 0);
   if (p->use_yolo) {
+    t_alt_stream = true;
+    struct AltOff { ~AltOff() { t_alt_stream = false; } } alt_off;
     const int dcap = 4096;
     std::vector<float> dets((size_t)B * dcap * 6);
     std::vector<int32_t> nd(B);
-    int rc = dani_yolo_detect_batch(e, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
-    if (rc) return rc;
+    rc = dani_yolo_detect_batch(e, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
+    if (rc) { t_keep_desc_on_device = false; return rc; }
     std::vector<const char*> cn, dn;
-    for (auto& s : S->class_names) cn.push_back(s.c_str());
-    for (auto& s : S->dynamic_names) dn.push_back(s.c_str());
+    for (auto& s : class_names) cn.push_back(s.c_str());
+    for (auto& s : dynamic_names) dn.push_back(s.c_str());
     std::vector<int32_t> tmp((size_t)(dcap + 1) * 4);
     for (int b = 0; b < B; b++) {
       const int k = yolo_dynamic_areas(dets.data() + (size_t)b * dcap * 6, nd[b], W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp.data(), dcap + 1);
@@ -1344,12 +1438,13 @@ int dani_frontend_batch(dani_engine* e, const uint8_t* gray, int32_t gray_stride
 
   // ---- 2. SuperPoint with the boxes as mvDynamicArea; descriptors stay resident for LightGlue
   const auto t1 = std::chrono::steady_clock::now();
-  t_keep_desc_on_device = true;
-  std::vector<int32_t> octave((size_t)B * cap);
-  std::vector<float> size((size_t)B * cap);
-  int rc = dani_sp_extract_batch(e, gray, on_device, B, W, H, gray_stride, &p->sp, boxes.empty() ? nullptr : boxes.data(),
-                                 boxes.empty() ? nullptr : offs.data(), p->lapping, kpts_xy, resp, octave.data(), size.data(),
-                                 desc, cap, n_out, mono_index);
+  t_sp_phase = 2;
+  t_defer_desc_sync = true;
+  rc = dani_sp_extract_batch(e, gray, on_device, B, W, H, gray_stride, &p->sp, boxes.empty() ? nullptr : boxes.data(),
+                             boxes.empty() ? nullptr : offs.data(), p->lapping, kpts_xy, resp, octave.data(), size.data(),
+                             desc, cap, n_out, mono_index);
+  t_sp_phase = 0;
+  t_defer_desc_sync = false;
   t_keep_desc_on_device = false;
   if (rc) return rc;
   S->ms[1] = ms_since(t1);
@@ -1368,6 +1463,7 @@ int dani_frontend_batch(dani_engine* e, const uint8_t* gray, int32_t gray_stride
   HIP_TRY(e, hipMemcpyAsync(c->d_kxy_all, c->d_kxy + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(e, hipStreamSynchronize(c->stream));
+  HIP_TRY(e, hipStreamSynchronize(c->stream2));   // overlapped descriptor read-back
   c->prev_n = n_out[B - 1];
   S->ms[2] = ms_since(t2);
   S->ms[3] = ms_since(t0);

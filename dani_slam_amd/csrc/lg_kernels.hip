@@ -37,75 +37,99 @@ struct LinArgs {
   float alpha;
 };
 
-constexpr int LIN_KC = 32, LIN_TT = 256, LIN_NCO = 64;
+constexpr int LIN_KC = 32, LIN_NCO = 64;
 
+// TT = tokens per workgroup.  256: wave = 64 out x 64 tok (2x2 accumulators); 128: wave = 64 out x 32 tok (2x1);
+// 64: waves arranged 2x2, wave = 32 out x 32 tok (1x1).  Smaller tiles trade operand reuse for more workgroups:
+// with ~17k tokens and 256 outputs a 256-token tile gives only 264 workgroups for 256 CUs (two rounds, 50 % idle).
+template <int TT>
 __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[LIN_KC * LIN_TT + LIN_KC * LIN_NCO];
+  constexpr int NCB = (TT >= 128) ? 2 : 1;          // cout blocks per wave
+  constexpr int NTB = (TT == 256) ? 2 : 1;          // token blocks per wave
+  constexpr int NX = LIN_KC * TT / 4 / 256;         // float4 of X per thread per chunk
+  __shared__ __attribute__((aligned(16))) float lds[LIN_KC * TT + LIN_KC * LIN_NCO];
   float* sX = lds;
-  float* sW = lds + LIN_KC * LIN_TT;
+  float* sW = lds + LIN_KC * TT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-  const int tok0 = blockIdx.x * LIN_TT, ot = blockIdx.y;
+  const int tok0 = blockIdx.x * TT, ot = blockIdx.y;
   const int K = a.K0 + a.K1, nchunks = K / LIN_KC;
   const float* wt = a.w + (size_t)ot * K * LIN_NCO;
+  const int wtok = (TT >= 128) ? wave * (TT / 4) : (wave & 1) * 32;   // wave's first token inside the tile
+  const int wout = (TT >= 128) ? 0 : (wave >> 1) * 32;                 // wave's first output row inside the 64
 
-  f32x16 acc[2][2];
+  f32x16 acc[NCB][NTB];
+  f32x16 acc2;   // TT == 64 only: second accumulator chain (odd k-pairs), see the note in attn_kernel
 #pragma unroll
-  for (int cb = 0; cb < 2; cb++)
+  for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float bv = a.bias[ot * LIN_NCO + cb * 32 + acc_row(r, h)];
-      acc[cb][0][r] = bv; acc[cb][1][r] = bv;
+      const float bv = a.bias[ot * LIN_NCO + wout + cb * 32 + acc_row(r, h)];
+#pragma unroll
+      for (int tb = 0; tb < NTB; tb++) acc[cb][tb][r] = bv;
+      acc2[r] = 0.0f;
     }
 
-  // staging: X chunk = 32 rows x 256 tokens = 2048 float4 (8 per thread); W chunk = 2048 floats = 512 float4 (2 per thread)
-  f32x4 px[8], pw[2];
-  int xoff[8];
+  f32x4 px[NX], pw[2];
+  int xoff[NX];
 #pragma unroll
-  for (int u = 0; u < 8; u++) {
+  for (int u = 0; u < NX; u++) {
     const int e = tid + 256 * u;
-    xoff[u] = (e >> 6) * a.ld + tok0 + 4 * (e & 63);   // row e/64, float4 column e%64
+    xoff[u] = (e / (TT / 4)) * a.ld + tok0 + 4 * (e % (TT / 4));
   }
 #define LIN_PREFETCH(ch_)                                                                            \
   {                                                                                                  \
     const int k0_ = (ch_) * LIN_KC;                                                                  \
     const float* src_ = (k0_ < a.K0) ? a.x0 + (size_t)k0_ * a.ld : a.x1 + (size_t)(k0_ - a.K0) * a.ld; \
-    _Pragma("unroll") for (int u = 0; u < 8; u++) px[u] = *reinterpret_cast<const f32x4*>(src_ + xoff[u]); \
+    _Pragma("unroll") for (int u = 0; u < NX; u++) px[u] = *reinterpret_cast<const f32x4*>(src_ + xoff[u]); \
     const f32x4* ws_ = reinterpret_cast<const f32x4*>(wt + (size_t)(ch_) * (LIN_KC * LIN_NCO));     \
     pw[0] = ws_[tid]; pw[1] = ws_[tid + 256];                                                        \
   }
-  const float* bA = sW + h * LIN_NCO + j;
-  const float* bB = sX + h * LIN_TT + wave * 64 + j;
+  const float* bA = sW + h * LIN_NCO + wout + j;
+  const float* bB = sX + h * TT + wtok + j;
 
   LIN_PREFETCH(0);
   for (int ch = 0; ch < nchunks; ch++) {
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 8; u++) reinterpret_cast<f32x4*>(sX)[tid + 256 * u] = px[u];
+    for (int u = 0; u < NX; u++) reinterpret_cast<f32x4*>(sX)[tid + 256 * u] = px[u];
     reinterpret_cast<f32x4*>(sW)[tid] = pw[0];
     reinterpret_cast<f32x4*>(sW)[tid + 256] = pw[1];
     __syncthreads();
     if (ch + 1 < nchunks) LIN_PREFETCH(ch + 1);
 #pragma unroll
     for (int kp = 0; kp < LIN_KC / 2; kp++) {
-      const float a0 = bA[(kp * 2) * LIN_NCO], a1 = bA[(kp * 2) * LIN_NCO + 32];
-      const float b0 = bB[(kp * 2) * LIN_TT], b1 = bB[(kp * 2) * LIN_TT + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float av[NCB], bv[NTB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) av[cb] = bA[(kp * 2) * LIN_NCO + cb * 32];
+#pragma unroll
+      for (int tb = 0; tb < NTB; tb++) bv[tb] = bB[(kp * 2) * TT + tb * 32];
+      if constexpr (NCB * NTB == 1) {
+        if (kp & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc2, 0, 0, 0);
+        else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+          for (int tb = 0; tb < NTB; tb++)
+            acc[cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[tb], acc[cb][tb], 0, 0, 0);
+      }
     }
   }
 #undef LIN_PREFETCH
+  if constexpr (NCB * NTB == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][0][r] += acc2[r];
+  }
 
 #pragma unroll
-  for (int tb = 0; tb < 2; tb++) {
-    const int tok = tok0 + wave * 64 + tb * 32 + j;
+  for (int tb = 0; tb < NTB; tb++) {
+    const int tok = tok0 + wtok + tb * 32 + j;
     const bool ok = tok < a.T;
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const int row = ot * LIN_NCO + cb * 32 + acc_row(r, h);   // even; row+1 is register r+1
+        const int row = ot * LIN_NCO + wout + cb * 32 + acc_row(r, h);   // even; row+1 is register r+1
         float v0 = acc[cb][tb][r], v1 = acc[cb][tb][r + 1];
         if (row < a.rot_rows && ok) {
           const int ip = (row & 63) >> 1;
@@ -134,47 +158,58 @@ void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   LinArgs a;
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w_packed; a.bias = bias_packed; a.y = y; a.res = res;
   a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;
-  dim3 grid((T + LIN_TT - 1) / LIN_TT, (OUT + LIN_NCO - 1) / LIN_NCO);
-  hipLaunchKernelGGL(linear_fm_kernel, grid, dim3(256), 0, s, a);
+  const int otiles = (OUT + LIN_NCO - 1) / LIN_NCO;
+  // largest token tile that still yields >= 4 workgroups per CU; else the smallest (load balance beats reuse)
+  auto wgs = [&](int tt) { return ((T + tt - 1) / tt) * otiles; };
+  if (wgs(256) >= 1024) hipLaunchKernelGGL(linear_fm_kernel<256>, dim3((T + 255) / 256, otiles), dim3(256), 0, s, a);
+  else if (wgs(128) >= 1024) hipLaunchKernelGGL(linear_fm_kernel<128>, dim3((T + 127) / 128, otiles), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(linear_fm_kernel<64>, dim3((T + 63) / 64, otiles), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm(512, eps 1e-5, affine) + exact GELU, in place on H [512][ld].  Block = 64 tokens x 4 feature quarters.
+// LayerNorm(512, eps 1e-5, affine) + exact GELU, in place on H [512][ld].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_gelu_kernel(float* hbuf, const float* gamma, const float* beta, int T, int ld) {
-  __shared__ float red[4][64];
-  const int lp = threadIdx.x & 63, q = threadIdx.x >> 6;
+// Block = 64 tokens x 16 feature groups (1024 threads): wave g holds features [32g, 32g+32) of 64 tokens in 32
+// VGPRs (high occupancy, one read + one write of the tensor); statistics are reduced across the 16 waves via LDS.
+__global__ __launch_bounds__(1024) void ln_gelu_kernel(float* hbuf, const float* gamma, const float* beta, int T, int ld) {
+  __shared__ float red[16][64];
+  const int lp = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int tok = blockIdx.x * 64 + lp;
   const bool ok = tok < T;
-  float v[128];
+  float v[32];
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 128; i++) {
-    v[i] = ok ? hbuf[(size_t)(q * 128 + i) * ld + tok] : 0.0f;
+  for (int i = 0; i < 32; i++) {
+    v[i] = ok ? hbuf[(size_t)(g * 32 + i) * ld + tok] : 0.0f;
     s += v[i];
   }
-  red[q][lp] = s;
+  red[g][lp] = s;
   __syncthreads();
-  const float mean = (red[0][lp] + red[1][lp] + red[2][lp] + red[3][lp]) * (1.0f / 512.0f);
+  float tot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) tot += red[k][lp];
+  const float mean = tot * (1.0f / 512.0f);
   __syncthreads();
   float s2 = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 128; i++) { const float d = v[i] - mean; s2 += d * d; }
-  red[q][lp] = s2;
+  for (int i = 0; i < 32; i++) { const float d = v[i] - mean; s2 += d * d; }
+  red[g][lp] = s2;
   __syncthreads();
-  const float var = (red[0][lp] + red[1][lp] + red[2][lp] + red[3][lp]) * (1.0f / 512.0f);
-  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  float tv = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) tv += red[k][lp];
+  const float rstd = 1.0f / sqrtf(tv * (1.0f / 512.0f) + 1e-5f);
   if (!ok) return;
 #pragma unroll
-  for (int i = 0; i < 128; i++) {
-    const int f = q * 128 + i;
+  for (int i = 0; i < 32; i++) {
+    const int f = g * 32 + i;
     const float y = (v[i] - mean) * rstd * gamma[f] + beta[f];
     hbuf[(size_t)f * ld + tok] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
   }
 }
 
 void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(ln_gelu_kernel, dim3((T + 63) / 64), dim3(256), 0, s, hbuf, gamma, beta, T, ld);
+  hipLaunchKernelGGL(ln_gelu_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -237,12 +272,13 @@ void launch_desc_to_fm(const float* desc_tm, const LgSet* sets, int nsets, int m
 // ---------------------------------------------------------------------------------------------
 constexpr int AT_STRIDE = 33;
 
-__global__ __launch_bounds__(256, 2) void attn_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
-                                                      const LgSet* sets, int cross, float scale) {
+template <int NW>   // waves (= 32-query blocks) per workgroup
+__global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
+                                                          const LgSet* sets, int cross, float scale) {
   __shared__ float sK[64 * AT_STRIDE];
   __shared__ float sV[64 * AT_STRIDE];
   const LgSet st = sets[blockIdx.z];
-  const int q0 = blockIdx.x * 128;
+  const int q0 = blockIdx.x * (32 * NW);
   if (q0 >= ((st.n + 31) & ~31)) return;
   const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -263,18 +299,19 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const float* Q, const floa
   float m = -1e30f, l = 0.0f;
 
   const int ntiles = (k_n + 31) / 32;
-  // staging: tile = 64 d x 32 keys; 512 float4 per matrix, 2 per thread
-  f32x4 pk[2], pv[2];
-  int soff[2], loff[2];
+  // staging: tile = 64 d x 32 keys; 512 float4 per matrix, NS per thread
+  constexpr int NS = 512 / (64 * NW);
+  f32x4 pk[NS], pv[NS];
+  int soff[NS], loff[NS];
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int e = tid + 256 * u, d = e >> 3, q4 = e & 7;
+  for (int u = 0; u < NS; u++) {
+    const int e = tid + 64 * NW * u, d = e >> 3, q4 = e & 7;
     soff[u] = d * ld + 4 * q4;
     loff[u] = d * AT_STRIDE + 4 * q4;
   }
 #define AT_PREFETCH(kt_)                                                               \
   {                                                                                    \
-    _Pragma("unroll") for (int u = 0; u < 2; u++) {                                    \
+    _Pragma("unroll") for (int u = 0; u < NS; u++) {                                   \
       pk[u] = *reinterpret_cast<const f32x4*>(Kh + (size_t)soff[u] + (kt_) * 32);      \
       pv[u] = *reinterpret_cast<const f32x4*>(Vh + (size_t)soff[u] + (kt_) * 32);      \
     }                                                                                  \
@@ -283,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const float* Q, const floa
   for (int kt = 0; kt < ntiles; kt++) {
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < NS; u++) {
 #pragma unroll
       for (int c = 0; c < 4; c++) { sK[loff[u] + c] = pk[u][c]; sV[loff[u] + c] = pv[u][c]; }
     }
@@ -291,6 +328,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const float* Q, const floa
     if (kt + 1 < ntiles) AT_PREFETCH(kt + 1);
 
     // S^T[key][query] = sum_d K[key][d] Q[query][d]
+    // (tried: hoisting all 32 operand reads + two accumulator chains behind sched_barrier -> 199 VGPRs, 2 waves/SIMD,
+    //  254 us vs 228 us per launch; the loss here is wave-count quantisation over the 1024 SIMDs, not the chain)
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; r++) s[r] = 0.0f;
@@ -339,7 +378,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const float* Q, const floa
 
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_n, int cross, float scale, hipStream_t s) {
-  hipLaunchKernelGGL(attn_kernel, dim3((max_n + 127) / 128, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, cross, scale);
+  const int max_np = (max_n + 31) & ~31;
+  if (((max_np + 127) / 128) * 4 * nsets >= 1024)
+    hipLaunchKernelGGL(attn_kernel<4>, dim3((max_np + 127) / 128, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, cross, scale);
+  else
+    hipLaunchKernelGGL(attn_kernel<2>, dim3((max_np + 63) / 64, 4, nsets), dim3(128), 0, s, Q, K, V, O, ld, sets, cross, scale);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64) void cell_nms_kernel(const float* prob, int PH,
                                                       const int32_t* box_offsets, int minBorder, float* slot_xyr,
                                                       int32_t* slot_count, int slot_stride) {
   __shared__ float conf[CELL_MAX_W * CELL_MAX_H];
+  __shared__ int sbox[256 * 4];   // this frame's dynamic boxes (first 256; the rest are read from global memory)
   __shared__ uint8_t grid[(CELL_MAX_H + 2 * NMS_D) * (CELL_MAX_W + 2 * NMS_D)];
   const int cell = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const CellRect c = cells[cell];
@@ -139,6 +140,8 @@ __global__ __launch_bounds__(64) void cell_nms_kernel(const float* prob, int PH,
   const float* pb = prob + (size_t)b * PH * PW;
   float* slot = slot_xyr + ((size_t)b * ncells + cell) * slot_stride * 3;
   const int nb0 = box_offsets ? box_offsets[b] : 0, nb1 = box_offsets ? box_offsets[b + 1] : 0;
+  const int nbl = min(nb1 - nb0, 256);
+  for (int i = lane; i < nbl * 4; i += 64) sbox[i] = boxes[4 * nb0 + i];
 
   int emitted = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -187,11 +190,18 @@ __global__ __launch_bounds__(64) void cell_nms_kernel(const float* prob, int PH,
       for (int y = 0; y < h; y++) {
         bool keep = lane < w && grid[(y + NMS_D) * gw + lane + NMS_D] == 2;
         const int px = lane + c.offX + minBorder, py = y + c.offY + minBorder;
-        if (keep)
-          for (int bi = nb0; bi < nb1; bi++) {
-            const int bx = boxes[4 * bi], by = boxes[4 * bi + 1], bw = boxes[4 * bi + 2], bh = boxes[4 * bi + 3];
-            if (bx <= px && px < bx + bw && by <= py && py < by + bh) { keep = false; break; }
+        if (__ballot(keep)) {
+          bool inside = false;
+          for (int bi = 0; bi < nbl; bi++) {               // uniform trip count, LDS broadcast reads
+            const int bx = sbox[4 * bi], by = sbox[4 * bi + 1], bw = sbox[4 * bi + 2], bh = sbox[4 * bi + 3];
+            inside |= (bx <= px && px < bx + bw && by <= py && py < by + bh);
           }
+          for (int bi = nb0 + nbl; bi < nb1; bi++) {
+            const int bx = boxes[4 * bi], by = boxes[4 * bi + 1], bw = boxes[4 * bi + 2], bh = boxes[4 * bi + 3];
+            inside |= (bx <= px && px < bx + bw && by <= py && py < by + bh);
+          }
+          keep = keep && !inside;
+        }
         const unsigned long long km = __ballot(keep);
         if (keep) {
           const int pos = emitted + __popcll(km & ((1ull << lane) - 1));

@@ -91,10 +91,10 @@ def load_library():
                                             C.POINTER(C.c_char_p), C.c_int32, _i32, _i32, C.c_int32]
     lib.dani_yolo_debug_raw.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int64]
     lib.dani_yolo_set_classes.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int32, C.POINTER(C.c_char_p), C.c_int32]
-    lib.dani_frontend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+    lib.dani_frontend_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.POINTER(_FrontendParams), _f, _f, _f, C.c_int32, _i32, _i32,
                                         _i32, C.c_int32, _i32, _i32, _f, C.c_int32, _i32]
-    lib.dani_frontend_reset.argtypes = [C.c_void_p]
+    lib.dani_frontend_reset.argtypes = [C.c_void_p, C.c_int32]
     lib.dani_frontend_timings.argtypes = [C.c_void_p, _f]
     lib.dani_host_distribute_octtree.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.c_int32, _i32, C.c_int32]
@@ -323,11 +323,12 @@ class Engine:
         dn = (C.c_char_p * len(dynamic_names))(*[x.encode() for x in dynamic_names])
         self._check(self.lib.dani_yolo_set_classes(self.h, cn, len(class_names), dn, len(dynamic_names)))
 
-    def frontend_reset(self):
-        self._check(self.lib.dani_frontend_reset(self.h))
+    def frontend_reset(self, sequence=0):
+        self._check(self.lib.dani_frontend_reset(self.h, sequence))
 
     def frontend_batch(self, gray, bgr=None, nfeatures=1024, iniTh=0.015, minTh=0.007, use_yolo=True, match_previous=True,
-                       lg_threshold=0.05, lapping=(0, 0), want_desc=True, device_ptrs=None, shape=None, box_cap=512, copy=True):
+                       lg_threshold=0.05, lapping=(0, 0), want_desc=True, device_ptrs=None, shape=None, box_cap=512, copy=True,
+                       sequence=0):
         """gray [B,H,W] u8 and bgr [B,H,W,3] u8 host arrays, or device_ptrs=(gray_ptr, bgr_ptr) + shape=(B,H,W).
         Returns a list of per-frame dicts: kpts, resp, desc (or None), mono_index, boxes [k,4], matches [K,2], scores.
         copy=False returns views into buffers that the next call overwrites."""
@@ -352,7 +353,9 @@ class Engine:
         p.use_yolo = int(use_yolo); p.yolo_score_thresh = 0.4; p.yolo_iou_thresh = 0.5
         p.match_previous = int(match_previous); p.lg_threshold = lg_threshold
         p.lapping[0], p.lapping[1] = int(lapping[0]), int(lapping[1])
-        bufs = getattr(self, "_fe_bufs", None)
+        if not hasattr(self, "_fe_bufs_by_seq"):
+            self._fe_bufs_by_seq = {}
+        bufs = self._fe_bufs_by_seq.get(sequence)
         key = (B, cap, box_cap, want_desc)
         if bufs is None or bufs[0] != key:
             bufs = (key, dict(k=np.empty((B, cap, 2), np.float32), r=np.empty((B, cap), np.float32),
@@ -360,9 +363,9 @@ class Engine:
                               n=np.zeros(B, np.int32), mono=np.zeros(B, np.int32),
                               boxes=np.zeros((B, box_cap, 4), np.int32), nb=np.zeros(B, np.int32),
                               m=np.zeros((B, cap, 2), np.int32), sc=np.zeros((B, cap), np.float32), ko=np.zeros(B, np.int32)))
-            self._fe_bufs = bufs
+            self._fe_bufs_by_seq[sequence] = bufs
         o = bufs[1]
-        rc = self.lib.dani_frontend_batch(self.h, gp, gs, bp, bs, on_dev, B, W, H, C.byref(p), _fp(o["k"]), _fp(o["r"]),
+        rc = self.lib.dani_frontend_batch(self.h, sequence, gp, gs, bp, bs, on_dev, B, W, H, C.byref(p), _fp(o["k"]), _fp(o["r"]),
                                           _fp(o["d"]) if want_desc else None, cap, _ip(o["n"]), _ip(o["mono"]),
                                           _ip(o["boxes"]), box_cap, _ip(o["nb"]), _ip(o["m"]), _fp(o["sc"]), cap, _ip(o["ko"]))
         self._check(rc)

@@ -205,7 +205,10 @@ typedef struct dani_frontend_params {
   int32_t lapping[2];      /* vLappingArea */
 } dani_frontend_params;
 
-/* One call = the whole per-frame front-end of the reference for B consecutive frames of ONE sequence, chained on the
+/* `sequence` selects one of any number of independent image sequences (cameras): each has its own stream, workspace
+ * and cached predecessor frame, so calls for DIFFERENT sequences may run concurrently from different host threads
+ * (their kernels interleave on the GPU and fill each other's tail / occupancy gaps).
+ * One call = the whole per-frame front-end of the reference for B consecutive frames of ONE sequence, chained on the
  * device: YoloDetection::Detect -> mvDynamicArea hand-off (src/Tracking.cc:1535-1539) -> SPextractor::operator()
  * -> LightGlue::matchDescriptors(previous frame, this frame).  Frame 0 of the call is matched against the last
  * frame of the previous call (features stay resident in HBM); the very first frame has no predecessor (k_out = 0).
@@ -215,13 +218,13 @@ typedef struct dani_frontend_params {
  * Outputs (host): keypoints / responses / descriptors as dani_sp_extract_batch (desc may be NULL: descriptors then
  * stay on the device only), dyn_boxes [B][box_cap][4] + n_boxes [B] (= mvDynamicArea per frame),
  * matches [B][match_cap][2] = (index in previous frame, index in this frame), scores, k_out [B]. */
-DANI_API int dani_frontend_batch(dani_engine* e, const uint8_t* gray, int32_t gray_stride, const uint8_t* bgr,
+DANI_API int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, int32_t gray_stride, const uint8_t* bgr,
                                  int32_t bgr_stride, int32_t imgs_on_device, int32_t B, int32_t width, int32_t height,
                                  const dani_frontend_params* p, float* kpts_xy, float* resp, float* desc, int32_t cap,
                                  int32_t* n_out, int32_t* mono_index, int32_t* dyn_boxes, int32_t box_cap,
                                  int32_t* n_boxes, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out);
 /* Forget the cached previous frame (start of a new sequence). */
-DANI_API int dani_frontend_reset(dani_engine* e);
+DANI_API int dani_frontend_reset(dani_engine* e, int32_t sequence);
 /* Stage wall times (ms) of the last dani_frontend_batch on this thread: [0] yolo, [1] superpoint, [2] lightglue, [3] total. */
 DANI_API int dani_frontend_timings(dani_engine* e, float* ms4);
 
