@@ -99,11 +99,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    from dani_slam_amd import sharding
     B = FRAMES_PER_GPU
-    # this rank's shard of the synthetic sequence: frames rank*B .. rank*B+B-1
+    shard = sharding.shard_frames(B * world, rank, world)   # this rank's block of the synthetic frames
     from oracle import yolo_oracle as _names   # class-name lists only (coco.names is not shipped by the reference)
-    frames = np.stack([synth.frame(rank * B + i) for i in range(B)])
-    frames_bgr = np.stack([synth.frame_bgr(rank * B + i) for i in range(B)])
+    frames = np.stack([synth.frame(i) for i in shard])
+    frames_bgr = np.stack([synth.frame_bgr(i) for i in shard])
     d_frames = torch.from_numpy(frames).to(dev)          # inputs resident in HBM before the timed region
     d_bgr = torch.from_numpy(frames_bgr).to(dev)
     weights = dict(synth.superpoint_weights(0)); weights.update(synth.lightglue_weights(0)); weights.update(synth.yolo_weights(0))
@@ -154,10 +155,7 @@ def main():
     eng.set_profiling(False)
     out = next(o for o in outs if o is not None)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    dt_max = sharding.reduce_max_seconds(dt, dev)
     nk = [len(o["kpts"]) for o in out]
 
     if rank == 0:

@@ -123,6 +123,15 @@ thread_local int t_sp_phase = 0;          // 0: whole extractor; 1: enqueue the 
 thread_local bool t_alt_stream = false;   // YOLO on the context's second stream
 thread_local bool t_defer_desc_sync = false;  // fused call: descriptor D2H runs on stream2 under LightGlue
 
+// stream2 carries YOLO's ~70 small dependent kernels while the main stream runs SuperPoint's few huge ones: give it
+// the highest priority so that its workgroups get the CU slots that free up first (otherwise the chain starves
+// behind conv1b's 9600 workgroups and the overlap buys nothing -- measured).
+hipError_t create_priority_stream(hipStream_t* s) {
+  int lo = 0, hi = 0;
+  if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+}
+
 Context* acquire(dani_engine* e) {
   if (t_borrowed) return t_borrowed;
   std::lock_guard<std::mutex> lk(e->mu);
@@ -258,7 +267,7 @@ int dani_engine_create(const dani_config* cfg, dani_engine** out) {
   for (int i = 0; i < e->cfg.n_contexts; i++) {
     Context* c = new Context();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
+        create_priority_stream(&c->stream2) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
     (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     for (auto& ev : c->lev) (void)hipEventCreate(&ev);
@@ -1265,11 +1274,17 @@ int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device
   HIP_TRY(e, hipStreamSynchronize(s));
   if (!t_alt_stream) { (void)hipEventElapsedTime(&c->ms[0], c->ev_y0, c->ev_y1); c->ms[4] = c->ms[0]; }
   int status = DANI_OK;
-  for (int b = 0; b < B; b++) {
-    const int k = yolo_nms_host(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->h_count[b], iou_thresh, dets6 + (size_t)b * cap * 6, cap);
-    n_out[b] = k;
-    if (k > cap) status = DANI_ERR_CAPACITY;
+  {  // greedy NMS is O(k n) per frame and independent across frames: one host thread per frame
+    auto work = [&](int b) {
+      n_out[b] = yolo_nms_host(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->h_count[b], iou_thresh, dets6 + (size_t)b * cap * 6, cap);
+    };
+    std::vector<std::thread> th;
+    for (int b = 1; b < B; b++) th.emplace_back(work, b);
+    work(0);
+    for (auto& t : th) t.join();
   }
+  for (int b = 0; b < B; b++)
+    if (n_out[b] > cap) status = DANI_ERR_CAPACITY;
   if (status != DANI_OK) return fail(e, status, "detection capacity %d too small", cap);
   return DANI_OK;
 }
@@ -1384,7 +1399,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   if (!S->ctx) {
     Context* c = new Context();
     HIP_TRY(e, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(e, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(e, create_priority_stream(&c->stream2));
     (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     for (auto& ev : c->lev) (void)hipEventCreate(&ev);
@@ -1422,13 +1437,23 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     std::vector<const char*> cn, dn;
     for (auto& s : class_names) cn.push_back(s.c_str());
     for (auto& s : dynamic_names) dn.push_back(s.c_str());
-    std::vector<int32_t> tmp((size_t)(dcap + 1) * 4);
+    std::vector<std::vector<int32_t>> tmp(B, std::vector<int32_t>((size_t)(dcap + 1) * 4));
+    std::vector<int> kk(B, 0);
+    {
+      auto work = [&](int b) {
+        kk[b] = yolo_dynamic_areas(dets.data() + (size_t)b * dcap * 6, nd[b], W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp[b].data(), dcap + 1);
+      };
+      std::vector<std::thread> th;
+      for (int b = 1; b < B; b++) th.emplace_back(work, b);
+      work(0);
+      for (auto& t : th) t.join();
+    }
     for (int b = 0; b < B; b++) {
-      const int k = yolo_dynamic_areas(dets.data() + (size_t)b * dcap * 6, nd[b], W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp.data(), dcap + 1);
+      const int k = kk[b];
       n_boxes[b] = k;
-      if (k > box_cap) return fail(e, DANI_ERR_CAPACITY, "frame %d has %d dynamic boxes (> %d)", b, k, box_cap);
-      memcpy(dyn_boxes + (size_t)b * box_cap * 4, tmp.data(), (size_t)k * 16);
-      boxes.insert(boxes.end(), tmp.begin(), tmp.begin() + (size_t)k * 4);
+      if (k > box_cap) { t_keep_desc_on_device = false; return fail(e, DANI_ERR_CAPACITY, "frame %d has %d dynamic boxes (> %d)", b, k, box_cap); }
+      memcpy(dyn_boxes + (size_t)b * box_cap * 4, tmp[b].data(), (size_t)k * 16);
+      boxes.insert(boxes.end(), tmp[b].begin(), tmp[b].begin() + (size_t)k * 4);
       offs[b + 1] = offs[b] + k;
     }
   } else if (n_boxes) {

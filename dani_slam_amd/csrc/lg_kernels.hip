@@ -46,13 +46,15 @@ template <int TT>
 __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   constexpr int NCB = (TT >= 128) ? 2 : 1;          // cout blocks per wave
   constexpr int NTB = (TT == 256) ? 2 : 1;          // token blocks per wave
-  constexpr int NX = LIN_KC * TT / 4 / 256;         // float4 of X per thread per chunk
-  __shared__ __attribute__((aligned(16))) float lds[LIN_KC * TT + LIN_KC * LIN_NCO];
+  constexpr int KC = (TT == 64) ? 64 : LIN_KC;       // rows of X per LDS chunk (deeper for the small tile: fewer barriers)
+  constexpr int NX = KC * TT / 4 / 256;             // float4 of X per thread per chunk
+  constexpr int NWF = KC * LIN_NCO / 4 / 256;       // float4 of W per thread per chunk
+  __shared__ __attribute__((aligned(16))) float lds[KC * TT + KC * LIN_NCO];
   float* sX = lds;
-  float* sW = lds + LIN_KC * TT;
+  float* sW = lds + KC * TT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
   const int tok0 = blockIdx.x * TT, ot = blockIdx.y;
-  const int K = a.K0 + a.K1, nchunks = K / LIN_KC;
+  const int K = a.K0 + a.K1, nchunks = K / KC;
   const float* wt = a.w + (size_t)ot * K * LIN_NCO;
   const int wtok = (TT >= 128) ? wave * (TT / 4) : (wave & 1) * 32;   // wave's first token inside the tile
   const int wout = (TT >= 128) ? 0 : (wave >> 1) * 32;                 // wave's first output row inside the 64
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
       acc2[r] = 0.0f;
     }
 
-  f32x4 px[NX], pw[2];
+  f32x4 px[NX], pw[NWF];
   int xoff[NX];
 #pragma unroll
   for (int u = 0; u < NX; u++) {
@@ -78,11 +80,11 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   }
 #define LIN_PREFETCH(ch_)                                                                            \
   {                                                                                                  \
-    const int k0_ = (ch_) * LIN_KC;                                                                  \
+    const int k0_ = (ch_) * KC;                                                                      \
     const float* src_ = (k0_ < a.K0) ? a.x0 + (size_t)k0_ * a.ld : a.x1 + (size_t)(k0_ - a.K0) * a.ld; \
     _Pragma("unroll") for (int u = 0; u < NX; u++) px[u] = *reinterpret_cast<const f32x4*>(src_ + xoff[u]); \
-    const f32x4* ws_ = reinterpret_cast<const f32x4*>(wt + (size_t)(ch_) * (LIN_KC * LIN_NCO));     \
-    pw[0] = ws_[tid]; pw[1] = ws_[tid + 256];                                                        \
+    const f32x4* ws_ = reinterpret_cast<const f32x4*>(wt + (size_t)(ch_) * (KC * LIN_NCO));         \
+    _Pragma("unroll") for (int u = 0; u < NWF; u++) pw[u] = ws_[tid + 256 * u];                      \
   }
   const float* bA = sW + h * LIN_NCO + wout + j;
   const float* bB = sX + h * TT + wtok + j;
@@ -92,12 +94,12 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NX; u++) reinterpret_cast<f32x4*>(sX)[tid + 256 * u] = px[u];
-    reinterpret_cast<f32x4*>(sW)[tid] = pw[0];
-    reinterpret_cast<f32x4*>(sW)[tid + 256] = pw[1];
+#pragma unroll
+    for (int u = 0; u < NWF; u++) reinterpret_cast<f32x4*>(sW)[tid + 256 * u] = pw[u];
     __syncthreads();
     if (ch + 1 < nchunks) LIN_PREFETCH(ch + 1);
 #pragma unroll
-    for (int kp = 0; kp < LIN_KC / 2; kp++) {
+    for (int kp = 0; kp < KC / 2; kp++) {
       float av[NCB], bv[NTB];
 #pragma unroll
       for (int cb = 0; cb < NCB; cb++) av[cb] = bA[(kp * 2) * LIN_NCO + cb * 32];

@@ -1,0 +1,60 @@
+"""Multi-GPU plumbing for the front-end: frames are independent units, so ranks take
+disjoint frame blocks with NO data-path collective.  The only exchange the design foresees is one all-gather of
+per-frame features (count, keypoints, responses, descriptors) for the multi-camera / batched-sequence LightGlue
+case, where a pair's two frames live on different GPUs.  `torch.distributed` is plumbing here: backend "nccl" is
+RCCL over xGMI on the MI355X node, "gloo" is used by the CPU tests.  ~1.06 MB per 1024-keypoint frame: one direct
+all-gather per batch (all 7 xGMI links of a GPU in parallel), not a ring of small messages.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_frames(n_frames: int, rank: int, world: int) -> range:
+    """Contiguous block of frame indices owned by `rank` (blocks differ by at most one frame)."""
+    base, rem = divmod(n_frames, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def reduce_max_seconds(dt: float, device=None) -> float:
+    """MAX over ranks of a wall time (bench.py contract).  No-op without an initialised process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(dt)
+    t = torch.tensor([dt], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allgather_features(kpts, resp, desc, cap: int, device=None):
+    """All-gather of one frame's features across ranks (RCCL all-gather on GPU tensors, gloo on CPU tensors).
+    kpts [n,2], resp [n], desc [n,256] (numpy or torch, n <= cap).  Returns a list (len = world size) of
+    (kpts, resp, desc) numpy triples.  Packing: one f32 slab of cap*(2+1+256)+1 floats per rank, count in slot 0,
+    so a single collective moves everything."""
+    import torch
+    import torch.distributed as dist
+    kpts = np.asarray(kpts, np.float32).reshape(-1, 2); resp = np.asarray(resp, np.float32).reshape(-1)
+    desc = np.asarray(desc, np.float32).reshape(-1, 256)
+    n = len(kpts)
+    assert n <= cap and len(resp) == n and len(desc) == n
+    slab = np.zeros(1 + cap * 259, np.float32)
+    slab[0] = n
+    slab[1:1 + 2 * n] = kpts.reshape(-1)
+    slab[1 + 2 * cap:1 + 2 * cap + n] = resp
+    slab[1 + 3 * cap:1 + 3 * cap + 256 * n] = desc.reshape(-1)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return [(kpts, resp, desc)]
+    dev = device or "cpu"
+    mine = torch.from_numpy(slab).to(dev)
+    out = torch.empty(world * slab.size, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    out = out.cpu().numpy().reshape(world, -1)
+    res = []
+    for r in range(world):
+        m = int(out[r, 0])
+        res.append((out[r, 1:1 + 2 * m].reshape(m, 2).copy(), out[r, 1 + 2 * cap:1 + 2 * cap + m].copy(),
+                    out[r, 1 + 3 * cap:1 + 3 * cap + 256 * m].reshape(m, 256).copy()))
+    return res

@@ -1,0 +1,62 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py (frame sharding, max-over-ranks timing) and the feature
+all-gather used for the multi-camera LightGlue case."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dani_slam_amd import sharding
+
+
+def test_shard_frames_partition():
+    for n, w in [(64, 8), (64, 1), (10, 4), (3, 8), (17, 2)]:
+        got = []
+        for r in range(w):
+            got += list(sharding.shard_frames(n, r, w))
+        assert got == list(range(n))
+        sizes = [len(sharding.shard_frames(n, r, w)) for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.RandomState(100 + rank)
+        n = 5 + 3 * rank
+        k = rng.rand(n, 2).astype(np.float32); r = rng.rand(n).astype(np.float32); d = rng.rand(n, 256).astype(np.float32)
+        allf = sharding.allgather_features(k, r, d, cap=16)
+        ok = len(allf) == world
+        for rr in range(world):
+            g = np.random.RandomState(100 + rr)
+            nn = 5 + 3 * rr
+            ek = g.rand(nn, 2).astype(np.float32); er = g.rand(nn).astype(np.float32); ed = g.rand(nn, 256).astype(np.float32)
+            ok = ok and np.array_equal(allf[rr][0], ek) and np.array_equal(allf[rr][1], er) and np.array_equal(allf[rr][2], ed)
+        mx = sharding.reduce_max_seconds(1.0 + rank)
+        frames = list(sharding.shard_frames(16, rank, world))
+        q.put((rank, ok, mx, frames))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_allgather_and_max():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps: p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in ps: p.join(timeout=60)
+    res.sort()
+    assert all(r[1] for r in res)
+    assert all(abs(r[2] - 2.0) < 1e-12 for r in res)                 # max over ranks of (1.0, 2.0)
+    assert res[0][3] + res[1][3] == list(range(16))
