@@ -41,6 +41,8 @@ enum ConvVariant {
   // YOLOv5s (SiLU): 6x6 stride-2 stem, 3x3 stride-2, 3x3, 1x1; "ROW32" = 8x32 tiles, "BLK16" = 16x16 tiles
   CONV6S2_ROW32_SILU = 4, CONV3S2_ROW32_SILU = 5, CONV3S2_BLK16_SILU = 6, CONV3_ROW32_SILU = 7,
   CONV3_BLK16_SILU = 8, CONV1_ROW32_SILU = 9, CONV1_BLK16_SILU = 10,
+  // small-grid variants: 8x16-pixel x 32-cout workgroups
+  CONV3_BLK16S_RELU = 11, CONV1_BLK16S_LINEAR = 12, CONV3_BLK16S_SILU = 13, CONV3S2_BLK16S_SILU = 14, CONV1_BLK16S_SILU = 15,
 };
 
 // tensor views for one conv launch: tensors may be channel slices of larger (concat) buffers
@@ -55,7 +57,7 @@ struct ConvLayerPlan {
   ConvVariant variant;
   int Cin, Cout, ksize;
   int CinPad = 0;        // Cin rounded up to the chunk size (the YOLO stem pads 3 -> 4 with a zero plane)
-  int cout_tiles;        // ceil(Cout / 64)
+  int cout_tiles;        // ceil(Cout / couts-per-workgroup)
   int CC;                // input channels per LDS chunk
   float* w_packed = nullptr;  // device, [cout_tile][chunk][cp][tap][cc][64]
   float* bias_packed = nullptr;  // device, cout_tiles * 64
@@ -66,7 +68,20 @@ struct ConvLayerPlan {
 void pack_conv_weights(const float* w_oihw, const float* bias, int Cin, int Cout, int ksize, int CC, int NCO,
                        float* w_packed, float* bias_packed);
 inline int conv_variant_cc(ConvVariant v) {
-  return (v == CONV1_BLK16_LINEAR || v == CONV1_ROW32_SILU || v == CONV1_BLK16_SILU) ? 32 : (v == CONV6S2_ROW32_SILU ? 4 : 8);
+  return (v == CONV1_BLK16_LINEAR || v == CONV1_ROW32_SILU || v == CONV1_BLK16_SILU || v == CONV1_BLK16S_LINEAR ||
+          v == CONV1_BLK16S_SILU) ? 32 : (v == CONV6S2_ROW32_SILU ? 4 : 8);
+}
+inline int conv_variant_nco(ConvVariant v) { return v >= CONV3_BLK16S_RELU ? 32 : 64; }   // couts per workgroup
+// the small-grid twin of a 16x16-tile variant (or the variant itself)
+inline ConvVariant conv_small_variant(ConvVariant v) {
+  switch (v) {
+    case CONV3_BLK16_RELU: return CONV3_BLK16S_RELU;
+    case CONV1_BLK16_LINEAR: return CONV1_BLK16S_LINEAR;
+    case CONV3_BLK16_SILU: return CONV3_BLK16S_SILU;
+    case CONV3S2_BLK16_SILU: return CONV3S2_BLK16S_SILU;
+    case CONV1_BLK16_SILU: return CONV1_BLK16S_SILU;
+    default: return v;
+  }
 }
 
 // ---- kernel launchers (all asynchronous on `s`) ------------------------------------------------

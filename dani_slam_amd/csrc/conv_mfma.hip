@@ -40,13 +40,13 @@ struct ConvArgs {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
-template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_>
+template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2>
 struct Cfg {
   static constexpr int KS = KS_, S = S_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_, ACT = ACT_;
   static constexpr bool POOL = POOL_;
   static constexpr int T = KS * KS;
   static constexpr int PAD = (KS == 1) ? 0 : (KS == 3) ? 1 : 2;   // 1x1 p0, 3x3 p1, 6x6 p2 (YOLOv5 stem)
-  static constexpr int NCB = 2, NCO = 64;
+  static constexpr int NCB = NCB_, NCO = 32 * NCB_;   // cout blocks per wave / couts per workgroup
   static constexpr int TH = 4 * NPB * PBH, TW = PBW;   // 4 waves stacked vertically (output pixels)
   static constexpr int LROWS = S * (TH - 1) + KS;
   static constexpr int XOFF = (KS == 1) ? 0 : PADX - PAD;          // LDS column of input col (S*px + kx - PAD)
@@ -208,6 +208,13 @@ using CfgRow32Silu      = Cfg<3, 1, 1, 32, 2, 8, ACT_SILU, false>;
 using CfgBlk16Silu      = Cfg<3, 1, 2, 16, 2, 8, ACT_SILU, false>;
 using CfgConv1Row32Silu = Cfg<1, 1, 1, 32, 2, 32, ACT_SILU, false>;
 using CfgConv1Blk16Silu = Cfg<1, 1, 2, 16, 2, 32, ACT_SILU, false>;
+// "small" variants for layers whose grid would not fill the chip: 8x16-pixel x 32-cout workgroups (one 32x32
+// accumulator per wave) -> 4x more, 4x shorter workgroups.  Same k order, so results are bit-identical.
+using CfgBlk16sRelu      = Cfg<3, 1, 2, 16, 1, 8, ACT_RELU, false, 1>;
+using CfgConv1Blk16s     = Cfg<1, 1, 2, 16, 1, 32, ACT_NONE, false, 1>;
+using CfgBlk16sSilu      = Cfg<3, 1, 2, 16, 1, 8, ACT_SILU, false, 1>;
+using CfgS2Blk16sSilu    = Cfg<3, 2, 2, 16, 1, 8, ACT_SILU, false, 1>;
+using CfgConv1Blk16sSilu = Cfg<1, 1, 2, 16, 1, 32, ACT_SILU, false, 1>;
 
 template <class C>
 static void launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
@@ -237,6 +244,11 @@ void launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV3_BLK16_SILU: launch_cfg<CfgBlk16Silu>(L, io, B, s); break;
     case CONV1_ROW32_SILU: launch_cfg<CfgConv1Row32Silu>(L, io, B, s); break;
     case CONV1_BLK16_SILU: launch_cfg<CfgConv1Blk16Silu>(L, io, B, s); break;
+    case CONV3_BLK16S_RELU: launch_cfg<CfgBlk16sRelu>(L, io, B, s); break;
+    case CONV1_BLK16S_LINEAR: launch_cfg<CfgConv1Blk16s>(L, io, B, s); break;
+    case CONV3_BLK16S_SILU: launch_cfg<CfgBlk16sSilu>(L, io, B, s); break;
+    case CONV3S2_BLK16S_SILU: launch_cfg<CfgS2Blk16sSilu>(L, io, B, s); break;
+    case CONV1_BLK16S_SILU: launch_cfg<CfgConv1Blk16sSilu>(L, io, B, s); break;
   }
 }
 

@@ -352,12 +352,17 @@ int dani_finalize_weights(dani_engine* e) {
     }
     ConvLayerPlan& L = e->plan[i];
     L.variant = kSpVariant[i];
+    if (i >= 6) {   // 1/8-resolution layers: switch to the small-tile twin when the grid would not fill the chip
+      const int tiles = ((e->cfg.max_height / 8 + 15) / 16) * ((e->cfg.max_width / 8 + 15) / 16);
+      if (e->cfg.max_batch * tiles * ((d.cout + 63) / 64) < 768) L.variant = conv_small_variant(L.variant);
+    }
     L.Cin = d.cin; L.Cout = d.cout; L.ksize = d.k; L.CinPad = d.cin;
     L.CC = conv_variant_cc(L.variant);
-    L.cout_tiles = (d.cout + 63) / 64;
-    L.w_packed_floats = (size_t)L.cout_tiles * 64 * d.cin * d.k * d.k;
-    std::vector<float> wp(L.w_packed_floats), bp((size_t)L.cout_tiles * 64);
-    pack_conv_weights(wi->second.data(), bi->second.data(), d.cin, d.cout, d.k, L.CC, 64, wp.data(), bp.data());
+    const int nco = conv_variant_nco(L.variant);
+    L.cout_tiles = (d.cout + nco - 1) / nco;
+    L.w_packed_floats = (size_t)L.cout_tiles * nco * d.cin * d.k * d.k;
+    std::vector<float> wp(L.w_packed_floats), bp((size_t)L.cout_tiles * nco);
+    pack_conv_weights(wi->second.data(), bi->second.data(), d.cin, d.cout, d.k, L.CC, nco, wp.data(), bp.data());
     HIP_TRY(e, hipMalloc((void**)&L.w_packed, wp.size() * 4)); e->weight_allocs.push_back(L.w_packed);
     HIP_TRY(e, hipMalloc((void**)&L.bias_packed, bp.size() * 4)); e->weight_allocs.push_back(L.bias_packed);
     HIP_TRY(e, hipMemcpy(L.w_packed, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
@@ -641,6 +646,11 @@ struct LgContext {
   std::vector<void*> dev_allocs, host_allocs;
   int last_nsets = 0;
   std::vector<LgSet> last_sets;
+  // profiling of the attention kernel (dominant kernel of the full front-end): events around its 18 launches
+  hipEvent_t aev[36] = {};
+  bool aev_ready = false;
+  float attn_ms = 0.0f;
+  double attn_flops = 0.0;
 };
 
 std::map<Context*, LgContext*> g_lg_ctx;  // guarded by engine mutex
@@ -822,8 +832,15 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
 }
 
 // the 9-layer forward + assignment statistics on stream s; inputs already in L->kpts / L->desc_tm / L->d_sets
-void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, hipStream_t s) {
+void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, hipStream_t s, bool prof) {
   const int ld = L->ld, max_np = round_up(max_n, 32);
+  if (prof && !L->aev_ready) { for (auto& ev : L->aev) (void)hipEventCreate(&ev); L->aev_ready = true; }
+  int ai = 0;
+  auto attn = [&](const float* Q, const float* K, const float* V, int cross, float scale) {
+    if (prof) (void)hipEventRecord(L->aev[ai++], s);
+    launch_attention(Q, K, V, L->ctx, ld, L->d_sets, nsets, max_n, cross, scale, s);
+    if (prof) (void)hipEventRecord(L->aev[ai++], s);
+  };
   launch_desc_to_fm(L->desc_tm, L->d_sets, nsets, max_np, L->x, ld, s);
   launch_posenc(L->kpts, L->d_sets, nsets, max_np, W->wr, L->cosb, L->sinb, ld, s);
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
@@ -833,13 +850,13 @@ void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, h
     const LgBlockW& S = W->self_[i]; const LgBlockW& C = W->cross_[i];
     // self block: Wqkv (+rotary) -> attention -> [out_proj folded into] ffn.0 -> LN+GELU -> ffn.3 + residual
     lin(S.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 512, 1.0f);
-    launch_attention(L->qkv, L->qkv + (size_t)256 * ld, L->qkv + (size_t)512 * ld, L->ctx, ld, L->d_sets, nsets, max_n, 0, 0.125f, s);
+    attn(L->qkv, L->qkv + (size_t)256 * ld, L->qkv + (size_t)512 * ld, 0, 0.125f);
     lin(S.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
     launch_ln_gelu(L->hbuf, S.ln_g, S.ln_b, T, ld, s);
     lin(S.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
     // cross block: [to_qk*s | to_v] in one GEMM -> attention over the partner set -> [to_out folded into] ffn.0 ...
     lin(C.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 0, 1.0f);
-    launch_attention(L->qkv, L->qkv, L->qkv + (size_t)256 * ld, L->ctx, ld, L->d_sets, nsets, max_n, 1, 1.0f, s);
+    attn(L->qkv, L->qkv, L->qkv + (size_t)256 * ld, 1, 1.0f);
     lin(C.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
     launch_ln_gelu(L->hbuf, C.ln_g, C.ln_b, T, ld, s);
     lin(C.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
@@ -925,7 +942,8 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
       HIP_TRY(e, hipMemcpyAsync(L->desc_tm + (size_t)st.tok_off * 256, d, (size_t)st.n * 1024, kind, s));
     }
   HIP_TRY(e, hipEventRecord(c->ev[0], s));
-  if (max_n > 0) lg_forward(W, L, 2 * P, max_n, T, s);
+  const bool prof = e->profiling;
+  if (max_n > 0) lg_forward(W, L, 2 * P, max_n, T, s, prof);
   HIP_TRY(e, hipEventRecord(c->ev[1], s));
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemcpyAsync(L->h_m0, L->m0, (size_t)T * 4, hipMemcpyDeviceToHost, s));
@@ -935,6 +953,14 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
   (void)hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]);
   c->ms[4] = c->ms[0];
   t_last_ctx = c;
+  if (prof && max_n > 0) {
+    float tot = 0.0f;
+    for (int i = 0; i < 36; i += 2) { float m = 0.0f; (void)hipEventElapsedTime(&m, L->aev[i], L->aev[i + 1]); tot += m; }
+    L->attn_ms = tot;
+    double fl = 0.0;   // algorithmic: per launch, per set: 4 heads x (QK^T + PV) = 2 * 2 * nq * nk * 256 flop
+    for (const LgSet& st : L->last_sets) fl += 9.0 * 4.0 * 256.0 * st.n * ((double)st.n + (double)st.partner_n);
+    L->attn_flops = fl;
+  }
   // mutual check + thresholds (filter_matches of the model at 0.1, then LightGlue::filterMatches, src/LightGlue.cpp:98-122)
   int status = DANI_OK;
   for (int p = 0; p < P; p++) {
@@ -965,6 +991,15 @@ int dani_lg_match(dani_engine* e, const float* kpts0, const float* desc0, int32_
   const int in_cap = std::max(n0, n1);
   return dani_lg_match_batch(e, 1, in_cap, 0, kpts0, desc0, &n0, kpts1, desc1, &n1, size0, size1, threshold, matches,
                              scores, cap, k_out);
+}
+
+int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches) {
+  LgContext* L = t_last_lg;
+  if (!e || !L) return DANI_ERR_INVALID;
+  if (total_ms) *total_ms = L->attn_ms;
+  if (total_flop) *total_flop = L->attn_flops;
+  if (launches) *launches = 18;
+  return DANI_OK;
 }
 
 int dani_lg_debug_fetch(dani_engine* e, int32_t set, float* desc_out, int32_t* m0, float* max0, int32_t cap) {
@@ -1052,12 +1087,17 @@ int yolo_pack(dani_engine* e, YoloWeights* W, const std::string& name, int cin, 
   YConv& yc = W->convs[name];
   ConvLayerPlan& L = yc.plan;
   L.variant = yolo_variant(k, s, scale, act);
+  if (scale >= 2) {   // 16x16-tile layers: small-tile twin when the grid would not fill the chip
+    const int tiles = ((kYH[scale] + 15) / 16) * ((kYW[scale] + 15) / 16);
+    if (e->cfg.max_batch * tiles * ((cout + 63) / 64) < 768) L.variant = conv_small_variant(L.variant);
+  }
   L.Cin = cin; L.Cout = cout; L.ksize = k;
   L.CC = conv_variant_cc(L.variant);
   L.CinPad = round_up(cin, L.CC);
-  L.cout_tiles = (cout + 63) / 64;
-  std::vector<float> wp((size_t)L.cout_tiles * 64 * L.CinPad * k * k), bp((size_t)L.cout_tiles * 64);
-  pack_conv_weights(wi->second.data(), bi->second.data(), cin, cout, k, L.CC, 64, wp.data(), bp.data());
+  const int nco = conv_variant_nco(L.variant);
+  L.cout_tiles = (cout + nco - 1) / nco;
+  std::vector<float> wp((size_t)L.cout_tiles * nco * L.CinPad * k * k), bp((size_t)L.cout_tiles * nco);
+  pack_conv_weights(wi->second.data(), bi->second.data(), cin, cout, k, L.CC, nco, wp.data(), bp.data());
   HIP_TRY(e, hipMalloc((void**)&L.w_packed, wp.size() * 4)); e->weight_allocs.push_back(L.w_packed);
   HIP_TRY(e, hipMalloc((void**)&L.bias_packed, bp.size() * 4)); e->weight_allocs.push_back(L.bias_packed);
   HIP_TRY(e, hipMemcpy(L.w_packed, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));

@@ -378,13 +378,137 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const float* Q, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Key-split variant: workgroup = 64 queries = 2 query blocks x 2 key halves (wave w: query block w&1, key half w>>1).
+// Each wave runs the online softmax over its half of the keys; the two partial (m, l, O) states of a query block are
+// merged through LDS at the end.  Twice as many, half as long waves: with ~2100 query blocks per launch on 1024
+// SIMDs the un-split kernel needs 3 rounds for 2.06 waves per SIMD (69 % balance), this one 5 half-rounds for 4.25
+// (82 %).  The two query blocks share every staged K/V tile.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
+                                                         const LgSet* sets, int cross, float scale) {
+  __shared__ float sKV[4 * 64 * AT_STRIDE];   // [key half][K | V][64 d][33]
+  const LgSet st = sets[blockIdx.z];
+  const int np = (st.n + 31) & ~31;
+  const int q0 = blockIdx.x * 64;
+  if (q0 >= np) return;
+  const int head = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int qb = wave & 1, kh = wave >> 1;
+  const int k_off = cross ? st.partner_off : st.tok_off, k_n = cross ? st.partner_n : st.n;
+  const int qi = q0 + qb * 32 + j;
+  const bool wave_active = (q0 + qb * 32) < np;              // wave-uniform: the last tile may hold one block only
+  const int qtok = st.tok_off + min(qi, np - 1);
+  const float* Qh = Q + (size_t)head * 64 * ld;
+  const float* Kh = K + (size_t)head * 64 * ld + k_off;
+  const float* Vh = V + (size_t)head * 64 * ld + k_off;
+  float* sK = sKV + (size_t)kh * 2 * 64 * AT_STRIDE;
+  float* sV = sK + 64 * AT_STRIDE;
+
+  float qreg[32];
+#pragma unroll
+  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * scale;
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
+  float m = -1e30f, l = 0.0f;
+
+  const int ntiles = (k_n + 31) / 32, half = (ntiles + 1) / 2;
+  // staging: per iteration 2 key tiles x (K, V) x 512 float4 = 2048 float4, 8 per thread
+  f32x4 pf[8];
+  const float* gsrc[8];      // row base of each staged float4 (K or V, row d, column 4*q4)
+  int loff[8], hsel[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int e = tid + 256 * u;             // [key half (2)][K/V (2)][d (64)][q4 (8)]
+    const int q4 = e & 7, d = (e >> 3) & 63, kv = (e >> 9) & 1, hh = e >> 10;
+    gsrc[u] = (kv ? Vh : Kh) + (size_t)d * ld + 4 * q4;
+    loff[u] = (hh * 2 + kv) * 64 * AT_STRIDE + d * AT_STRIDE + 4 * q4;
+    hsel[u] = hh * half;
+  }
+  // a key half may hold one tile fewer than the other: its extra load is clamped to the last tile and never used
+#define ATK_PREFETCH(it_)                                                                          \
+  {                                                                                                \
+    _Pragma("unroll") for (int u = 0; u < 8; u++)                                                  \
+      pf[u] = *reinterpret_cast<const f32x4*>(gsrc[u] + min(hsel[u] + (it_), ntiles - 1) * 32);    \
+  }
+  ATK_PREFETCH(0);
+  for (int it = 0; it < half; it++) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) sKV[loff[u] + c] = pf[u][c];
+    }
+    __syncthreads();
+    if (it + 1 < half) ATK_PREFETCH(it + 1);
+    const int kt = kh * half + it;                        // this wave's key tile
+    if (wave_active && kt < ntiles) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 32; t++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(2 * t + h) * AT_STRIDE + j], qreg[t], s, 0, 0, 0);
+      const int kbase = kt * 32;
+      float mx = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        if (kbase + acc_row(r, h) >= k_n) s[r] = -1e30f;
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __expf(m - m_new);
+      float ls = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = __expf(s[r] - m_new); ls += s[r]; }
+      l = l * alpha + ls;
+      m = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = acc_row(r, h);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[j * AT_STRIDE + key], s[r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(32 + j) * AT_STRIDE + key], s[r], o[1], 0, 0, 0);
+      }
+    }
+  }
+#undef ATK_PREFETCH
+  // ---- merge the two key halves of each query block through LDS (reusing the tile buffers)
+  __syncthreads();
+  float* xch = sKV + (size_t)qb * (64 * 34);           // per query block: 64 lanes x 34 floats
+  if (kh == 1) {
+    float* p = xch + lane * 34;
+    p[0] = m; p[1] = l;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { p[2 + r] = o[0][r]; p[18 + r] = o[1][r]; }
+  }
+  __syncthreads();
+  if (kh == 0 && qi < np) {
+    const float* p = xch + lane * 34;
+    const float m1 = p[0], l1 = p[1];
+    const float mm = fmaxf(m, m1);
+    const float a0 = __expf(m - mm), a1 = __expf(m1 - mm);
+    const float lt0 = l * a0 + l1 * a1;
+    const float lt = lt0 + __shfl_xor(lt0, 32);
+    const float inv = (lt > 0.0f && qi < st.n) ? 1.0f / lt : 0.0f;    // padding queries and empty key sets -> 0
+    float* Oh = O + (size_t)head * 64 * ld + st.tok_off + qi;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      Oh[(size_t)acc_row(r, h) * ld] = (o[0][r] * a0 + p[2 + r] * a1) * inv;
+      Oh[(size_t)(32 + acc_row(r, h)) * ld] = (o[1][r] * a0 + p[18 + r] * a1) * inv;
+    }
+  }
+}
+
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_n, int cross, float scale, hipStream_t s) {
   const int max_np = (max_n + 31) & ~31;
   if (((max_np + 127) / 128) * 4 * nsets >= 1024)
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_np + 127) / 128, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, cross, scale);
   else
-    hipLaunchKernelGGL(attn_kernel<2>, dim3((max_np + 63) / 64, 4, nsets), dim3(128), 0, s, Q, K, V, O, ld, sets, cross, scale);
+    hipLaunchKernelGGL(attn_ks_kernel, dim3((max_np + 63) / 64, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, cross, scale);
 }
 
 // ---------------------------------------------------------------------------------------------

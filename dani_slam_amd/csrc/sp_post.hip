@@ -282,14 +282,23 @@ __global__ __launch_bounds__(256) void desc_sample_kernel(const float* desc_nhwc
   sampled[((size_t)b * cap + i) * 256 + c] = v;
 }
 
-// one block per frame, thread = channel: sequential fma chain over the keypoints (canonical order)
+// one block per frame, thread = channel: sequential fma chain over the keypoints (canonical order).  The chain is
+// serial by definition, but its loads are not: 32 rows are fetched ahead of the 32 dependent fmas that consume them.
 __global__ __launch_bounds__(256) void desc_colnorm_kernel(const float* sampled, const int32_t* nk, int cap,
                                                            float* dn) {
   const int b = blockIdx.x, c = threadIdx.x;
   const int n = nk[b];
   const float* s = sampled + (size_t)b * cap * 256 + c;
   float acc = 0.0f;
-  for (int i = 0; i < n; i++) {
+  int i = 0;
+  for (; i + 32 <= n; i += 32) {
+    float v[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) v[k] = s[(size_t)(i + k) * 256];
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc = __builtin_fmaf(v[k], v[k], acc);
+  }
+  for (; i < n; i++) {
     const float v = s[(size_t)i * 256];
     acc = __builtin_fmaf(v, v, acc);
   }

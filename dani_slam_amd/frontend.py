@@ -84,6 +84,7 @@ def load_library():
     lib.dani_sp_debug_layer.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int64]
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
+    lib.dani_lg_attention_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
     lib.dani_lg_debug_fetch.argtypes = [C.c_void_p, C.c_int32, _f, _i32, _f, C.c_int32]
     lib.dani_yolo_detect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_float, C.c_float, _f, C.c_int32, _i32]
@@ -287,6 +288,12 @@ class Engine:
             out = np.zeros((1, cap, w), np.float32); out[0, :len(a)] = np.asarray(a, np.float32).reshape(-1, w); return out
         return self.lg_match_batch(pad(kpts0, 2), pad(desc0, 256), [n0], pad(kpts1, 2), pad(desc1, 256), [n1],
                                    size0, size1, threshold)[0]
+
+    def lg_attention_profile(self):
+        """(total ms, total algorithmic flop, launches) of the attention kernel in the last LightGlue call (profiling on)."""
+        ms = C.c_float(0); fl = C.c_double(0); n = C.c_int32(0)
+        self._check(self.lib.dani_lg_attention_profile(self.h, C.byref(ms), C.byref(fl), C.byref(n)))
+        return ms.value, fl.value, n.value
 
     def lg_debug_fetch(self, set_index, n):
         d = np.empty((n, 256), np.float32); m0 = np.empty(n, np.int32); mx = np.empty(n, np.float32)

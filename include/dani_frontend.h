@@ -157,6 +157,10 @@ DANI_API int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int3
                                  const int32_t* n1, const float* size0, const float* size1, float threshold,
                                  int32_t* matches, float* scores, int32_t cap, int32_t* k_out);
 
+/* With dani_set_profiling(e, 1): summed duration (HIP events on the engine's stream) and algorithmic FLOP of the 18
+ * attention-kernel launches of the last LightGlue call on this thread (bench.py roofline of the dominant kernel). */
+DANI_API int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches);
+
 /* Test hook: final descriptors (after the 9 layers) of keypoint set `set` (2*pair + side) of the last LightGlue
  * call on this thread, as [n][256] f32, and the raw row results (best column and log-score per query row). */
 DANI_API int dani_lg_debug_fetch(dani_engine* e, int32_t set, float* desc_out, int32_t* m0, float* max0, int32_t cap);

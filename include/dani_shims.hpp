@@ -7,7 +7,10 @@
 #include <opencv2/core/core.hpp>
 
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
+#include <map>
+#include <string>
 #include <mutex>
 #include <vector>
 
@@ -110,4 +113,81 @@ class SPextractor {
 typedef SPextractor ORBextractor;   // include/SPextractor.h:100
 #endif
 
+// Replaces class LightGlue, include/LightGlue.h:11-36.  Construction is O(1) (the reference jit::loads the blob in
+// every constructor: 13 LGmatcher constructions per frame path + one per stereo frame, quirk Q12).  The three call
+// sites pass pointer + count instead of torch::Tensor (src/Frame.cc:823-860, src/LGmatcher.cpp:299-314, :971-983):
+//     lg.matchDescriptors(mvKeys, mDescriptors.ptr<float>(), mDescriptors.rows,
+//                         mvKeysRight, mDescriptorsRight.ptr<float>(), mDescriptorsRight.rows,
+//                         (float)imgWidth, (float)imgHeight, (float)imgWidth, (float)imgHeight);
+class LightGlue {
+ public:
+  LightGlue() { dani_shim::engine(); }
+  ~LightGlue() {}
+  // size w/h <= 0 selects the reference's size.numel()==0 branch (1 + max - min of the keypoints)
+  std::vector<cv::DMatch> matchDescriptors(const std::vector<cv::KeyPoint>& keypoints1, const float* descriptors1, int n1,
+                                           const std::vector<cv::KeyPoint>& keypoints2, const float* descriptors2, int n2,
+                                           float w1, float h1, float w2, float h2, float threshold = 0.05f) {
+    std::vector<cv::DMatch> out;
+    if (n1 <= 0 || n2 <= 0) return out;
+    std::vector<float> k1(2 * (size_t)n1), k2(2 * (size_t)n2);
+    for (int i = 0; i < n1; i++) { k1[2 * i] = keypoints1[i].pt.x; k1[2 * i + 1] = keypoints1[i].pt.y; }   // keypointsToTensor
+    for (int i = 0; i < n2; i++) { k2[2 * i] = keypoints2[i].pt.x; k2[2 * i + 1] = keypoints2[i].pt.y; }
+    const float s1[2] = {w1, h1}, s2[2] = {w2, h2};
+    const int cap = n1;
+    std::vector<int32_t> m(2 * (size_t)cap);
+    std::vector<float> sc(cap);
+    int32_t k = 0;
+    const int rc = dani_lg_match(dani_shim::engine(), k1.data(), descriptors1, n1, k2.data(), descriptors2, n2,
+                                 w1 > 0 ? s1 : nullptr, w2 > 0 ? s2 : nullptr, threshold, m.data(), sc.data(), cap, &k);
+    if (rc != DANI_OK) { std::cerr << dani_last_error(dani_shim::engine()) << std::endl; return out; }
+    out.reserve(k);
+    for (int i = 0; i < k; i++) out.emplace_back(m[2 * i], m[2 * i + 1], sc[i]);   // DMatch(queryIdx, trainIdx, distance = score)
+    return out;
+  }
+};
+
 }  // namespace ORB_SLAM3
+
+// Replaces class YoloDetection, include/YoloDetect.h:16-41 (global namespace, as in the reference).
+class YoloDetection {
+ public:
+  YoloDetection() {
+    dani_shim::engine();
+    std::ifstream f("coco.names");                 // src/YoloDetect.cpp:12-16
+    std::string name;
+    while (std::getline(f, name)) mClassnames.push_back(name);
+    mvDynamicNames = {"person", "car", "motorbike", "bus", "train", "truck", "boat", "bird", "cat",
+                      "dog", "horse", "sheep", "crow", "bear"};   // :17-18
+  }
+  ~YoloDetection() {}
+  void GetImage(cv::Mat& RGB) { mRGB = RGB; }
+  void ClearImage() { mRGB = 0; }
+  void ClearArea() { mvPersonArea.clear(); }
+  bool Detect() {                                  // src/YoloDetect.cpp:27-82
+    if (mRGB.empty()) { std::cout << "Read RGB failed!" << std::endl; return false; }
+    const int cap = 4096;
+    std::vector<float> dets(6 * (size_t)cap);
+    int32_t n = 0;
+    if (dani_yolo_detect(dani_shim::engine(), mRGB.data, mRGB.cols, mRGB.rows, (int)mRGB.step, 0.4f, 0.5f, dets.data(), cap, &n) != DANI_OK) {
+      std::cerr << dani_last_error(dani_shim::engine()) << std::endl; return true;
+    }
+    if (n > 0) {
+      std::vector<const char*> cn, dn;
+      for (auto& s : mClassnames) cn.push_back(s.c_str());
+      for (auto& s : mvDynamicNames) dn.push_back(s.c_str());
+      std::vector<int32_t> rects(4 * (size_t)n), dyn(4 * (size_t)(n + 1));
+      const int k = dani_host_dynamic_areas(dets.data(), n, mRGB.cols, mRGB.rows, cn.data(), (int)cn.size(), dn.data(),
+                                            (int)dn.size(), rects.data(), dyn.data(), n + 1);
+      for (int i = 0; i < n; i++)
+        mmDetectMap[mClassnames[(int)dets[6 * i + 5]]].push_back(cv::Rect2i(rects[4 * i], rects[4 * i + 1], rects[4 * i + 2], rects[4 * i + 3]));
+      mvDynamicArea.clear();
+      for (int i = 0; i < k; i++) mvDynamicArea.push_back(cv::Rect2i(dyn[4 * i], dyn[4 * i + 1], dyn[4 * i + 2], dyn[4 * i + 3]));
+    }
+    return true;
+  }
+  std::vector<cv::Rect2i> mvPersonArea = {};
+  cv::Mat mRGB, mDepth;
+  std::vector<std::string> mClassnames, mvDynamicNames;
+  std::vector<cv::Rect2i> mvDynamicArea;
+  std::map<std::string, std::vector<cv::Rect2i>> mmDetectMap;
+};

@@ -16,7 +16,7 @@ import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-dom = sys.argv[2] if len(sys.argv) > 2 else "Cfg<3, 1, 32, 2, 8, true, true>"
+dom = sys.argv[2] if len(sys.argv) > 2 else "attn_kernel"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
