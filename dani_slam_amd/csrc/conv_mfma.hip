@@ -215,6 +215,10 @@ using CfgConv1Blk16s     = Cfg<1, 1, 2, 16, 1, 32, ACT_NONE, false, 1>;
 using CfgBlk16sSilu      = Cfg<3, 1, 2, 16, 1, 8, ACT_SILU, false, 1>;
 using CfgS2Blk16sSilu    = Cfg<3, 2, 2, 16, 1, 8, ACT_SILU, false, 1>;
 using CfgConv1Blk16sSilu = Cfg<1, 1, 2, 16, 1, 32, ACT_SILU, false, 1>;
+// "narrow" 8x32-tile variants for layers with <= 32 output channels (YOLO stem and the first C3): 32 couts per WG
+using CfgStem6Row32n     = Cfg<6, 2, 1, 32, 2, 4, ACT_SILU, false, 1>;
+using CfgRow32nSilu      = Cfg<3, 1, 1, 32, 2, 8, ACT_SILU, false, 1>;
+using CfgConv1Row32nSilu = Cfg<1, 1, 1, 32, 2, 32, ACT_SILU, false, 1>;
 
 template <class C>
 static void launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
@@ -249,6 +253,9 @@ void launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV3_BLK16S_SILU: launch_cfg<CfgBlk16sSilu>(L, io, B, s); break;
     case CONV3S2_BLK16S_SILU: launch_cfg<CfgS2Blk16sSilu>(L, io, B, s); break;
     case CONV1_BLK16S_SILU: launch_cfg<CfgConv1Blk16sSilu>(L, io, B, s); break;
+    case CONV6S2_ROW32N_SILU: launch_cfg<CfgStem6Row32n>(L, io, B, s); break;
+    case CONV3_ROW32N_SILU: launch_cfg<CfgRow32nSilu>(L, io, B, s); break;
+    case CONV1_ROW32N_SILU: launch_cfg<CfgConv1Row32nSilu>(L, io, B, s); break;
   }
 }
 

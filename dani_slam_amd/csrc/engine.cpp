@@ -9,6 +9,8 @@
 #include "../../include/dani_frontend.h"
 
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -115,6 +117,75 @@ int fail(dani_engine* e, int code, const char* fmt, ...) {
     if (_st != hipSuccess)                                                                          \
       return fail((e), DANI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_st), __FILE__, __LINE__); \
   } while (0)
+
+// Small persistent worker pool for the per-frame host stages (quadtree, NMS, box refinement): one pool per calling
+// thread, so concurrent sequences never share one.  Spawning std::threads per call cost ~150 us per stage.
+class HostPool {
+ public:
+  explicit HostPool(int workers) {
+    for (int i = 0; i < workers; i++) th_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // runs fn(0..count-1); the caller takes part; returns when all are done
+  void run(int count, const std::function<void(int)>& fn) {
+    if (count <= 1 || th_.empty()) { for (int i = 0; i < count; i++) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; count_ = count; next_ = 0; remaining_ = count; gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return remaining_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      int i;
+      const std::function<void(int)>* f;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!fn_ || next_ >= count_) return;
+        i = next_++; f = fn_;
+      }
+      (*f)(i);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--remaining_ == 0) done_.notify_all();
+      }
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int count_ = 0, next_ = 0, remaining_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+HostPool& host_pool() {
+  thread_local HostPool pool(7);
+  return pool;
+}
 
 thread_local Context* t_last_ctx = nullptr;
 thread_local Context* t_borrowed = nullptr;     // set by dani_frontend_batch: nested ABI calls reuse its context
@@ -469,16 +540,10 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   int status = DANI_OK;
   // the quadtree of each frame is independent: one host thread per frame (it is ~90 us of serial work per frame)
   std::vector<std::vector<int>> sels(B);
-  {
-    auto work = [&](int b) {
-      const HostKey* keys = reinterpret_cast<const HostKey*>(c->h_cand + (size_t)b * CAND_CAP * 3);
-      distribute_octtree(keys, c->h_cand_count[b], minBorderX, maxBorderX, minBorderY, maxBorderY, N, sels[b]);
-    };
-    std::vector<std::thread> th;
-    for (int b = 1; b < B; b++) th.emplace_back(work, b);
-    work(0);
-    for (auto& t : th) t.join();
-  }
+  host_pool().run(B, [&](int b) {
+    const HostKey* keys = reinterpret_cast<const HostKey*>(c->h_cand + (size_t)b * CAND_CAP * 3);
+    distribute_octtree(keys, c->h_cand_count[b], minBorderX, maxBorderX, minBorderY, maxBorderY, N, sels[b]);
+  });
   for (int b = 0; b < B; b++) {
     const HostKey* keys = reinterpret_cast<const HostKey*>(c->h_cand + (size_t)b * CAND_CAP * 3);
     const std::vector<int>& sel = sels[b];
@@ -1087,6 +1152,11 @@ int yolo_pack(dani_engine* e, YoloWeights* W, const std::string& name, int cin, 
   YConv& yc = W->convs[name];
   ConvLayerPlan& L = yc.plan;
   L.variant = yolo_variant(k, s, scale, act);
+  if (cout <= 32) {   // narrow twins: do not compute 32 zero-padded output channels
+    if (L.variant == CONV6S2_ROW32_SILU) L.variant = CONV6S2_ROW32N_SILU;
+    else if (L.variant == CONV3_ROW32_SILU) L.variant = CONV3_ROW32N_SILU;
+    else if (L.variant == CONV1_ROW32_SILU) L.variant = CONV1_ROW32N_SILU;
+  }
   if (scale >= 2) {   // 16x16-tile layers: small-tile twin when the grid would not fill the chip
     const int tiles = ((kYH[scale] + 15) / 16) * ((kYW[scale] + 15) / 16);
     if (e->cfg.max_batch * tiles * ((cout + 63) / 64) < 768) L.variant = conv_small_variant(L.variant);
@@ -1314,15 +1384,10 @@ int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device
   HIP_TRY(e, hipStreamSynchronize(s));
   if (!t_alt_stream) { (void)hipEventElapsedTime(&c->ms[0], c->ev_y0, c->ev_y1); c->ms[4] = c->ms[0]; }
   int status = DANI_OK;
-  {  // greedy NMS is O(k n) per frame and independent across frames: one host thread per frame
-    auto work = [&](int b) {
-      n_out[b] = yolo_nms_host(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->h_count[b], iou_thresh, dets6 + (size_t)b * cap * 6, cap);
-    };
-    std::vector<std::thread> th;
-    for (int b = 1; b < B; b++) th.emplace_back(work, b);
-    work(0);
-    for (auto& t : th) t.join();
-  }
+  // greedy NMS is O(k n) per frame and independent across frames
+  host_pool().run(B, [&](int b) {
+    n_out[b] = yolo_nms_host(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->h_count[b], iou_thresh, dets6 + (size_t)b * cap * 6, cap);
+  });
   for (int b = 0; b < B; b++)
     if (n_out[b] > cap) status = DANI_ERR_CAPACITY;
   if (status != DANI_OK) return fail(e, status, "detection capacity %d too small", cap);
@@ -1479,15 +1544,9 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     for (auto& s : dynamic_names) dn.push_back(s.c_str());
     std::vector<std::vector<int32_t>> tmp(B, std::vector<int32_t>((size_t)(dcap + 1) * 4));
     std::vector<int> kk(B, 0);
-    {
-      auto work = [&](int b) {
-        kk[b] = yolo_dynamic_areas(dets.data() + (size_t)b * dcap * 6, nd[b], W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp[b].data(), dcap + 1);
-      };
-      std::vector<std::thread> th;
-      for (int b = 1; b < B; b++) th.emplace_back(work, b);
-      work(0);
-      for (auto& t : th) t.join();
-    }
+    host_pool().run(B, [&](int b) {
+      kk[b] = yolo_dynamic_areas(dets.data() + (size_t)b * dcap * 6, nd[b], W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp[b].data(), dcap + 1);
+    });
     for (int b = 0; b < B; b++) {
       const int k = kk[b];
       n_boxes[b] = k;

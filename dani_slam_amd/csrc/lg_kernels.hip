@@ -46,7 +46,7 @@ template <int TT>
 __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   constexpr int NCB = (TT >= 128) ? 2 : 1;          // cout blocks per wave
   constexpr int NTB = (TT == 256) ? 2 : 1;          // token blocks per wave
-  constexpr int KC = (TT == 64) ? 64 : LIN_KC;       // rows of X per LDS chunk (deeper for the small tile: fewer barriers)
+  constexpr int KC = (TT <= 128) ? 64 : LIN_KC;      // rows of X per LDS chunk (deeper for the small tiles: fewer barriers)
   constexpr int NX = KC * TT / 4 / 256;             // float4 of X per thread per chunk
   constexpr int NWF = KC * LIN_NCO / 4 / 256;       // float4 of W per thread per chunk
   __shared__ __attribute__((aligned(16))) float lds[KC * TT + KC * LIN_NCO];

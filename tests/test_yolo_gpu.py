@@ -26,7 +26,7 @@ def engine(sp_weights, yw):
 
 
 def test_raw_head_and_dets_match_oracle(engine, yw):
-    img = synth.frame_bgr(0)
+    img = synth.frame_bgr(1)
     x = yo.preprocess(img)
     preds, taps = yo.network(yw, x, want_taps=True)
     dets_ref = yo.non_max_suppression(preds, 0.4, 0.5)
@@ -40,7 +40,7 @@ def test_raw_head_and_dets_match_oracle(engine, yw):
     assert np.array_equal(dets, dets_ref)
 
 
-@pytest.mark.parametrize("i", [1, 2, 3])
+@pytest.mark.parametrize("i", [4, 2, 6])
 def test_detect_and_dynamic_areas(engine, yw, i):
     from dani_slam_amd import frontend
     img = synth.frame_bgr(i)
@@ -54,7 +54,7 @@ def test_detect_and_dynamic_areas(engine, yw, i):
 
 
 def test_batch_and_other_thresholds(engine, yw):
-    imgs = np.stack([synth.frame_bgr(i) for i in (4, 5, 6)])
+    imgs = np.stack([synth.frame_bgr(i) for i in (4, 5, 1)])
     res = engine.yolo_detect_batch(imgs, 0.3, 0.45)
     for b in range(3):
         preds = yo.network(yw, yo.preprocess(imgs[b]))
