@@ -407,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
 
   float qreg[32];
 #pragma unroll
-  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * scale;
+  // softmax runs in base 2: log2(e) is folded into the query scale so that exp() is a bare v_exp_f32
+  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * (scale * 1.44269504088896341f);
   f32x16 o[2];
 #pragma unroll
   for (int r = 0; r < 16; r++) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
@@ -450,22 +451,27 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
 #pragma unroll
       for (int t = 0; t < 32; t++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(2 * t + h) * AT_STRIDE + j], qreg[t], s, 0, 0, 0);
       const int kbase = kt * 32;
-      float mx = -1e30f;
+      if (kbase + 32 > k_n) {                               // only the last key tile can hold padding keys
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        if (kbase + acc_row(r, h) >= k_n) s[r] = -1e30f;
-        mx = fmaxf(mx, s[r]);
+        for (int r = 0; r < 16; r++)
+          if (kbase + acc_row(r, h) >= k_n) s[r] = -1e30f;
       }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m, mx);
-      const float alpha = __expf(m - m_new);
       float ls = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; r++) { s[r] = __expf(s[r] - m_new); ls += s[r]; }
-      l = l * alpha + ls;
-      m = m_new;
+      for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ls += s[r]; }
+      if (__ballot(m_new > m)) {                            // rescale only when some query's running max moved
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        l *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; r++) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        for (int r = 0; r < 16; r++) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      }
+      l += ls;
+      m = m_new;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int key = acc_row(r, h);
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
     const float* p = xch + lane * 34;
     const float m1 = p[0], l1 = p[1];
     const float mm = fmaxf(m, m1);
-    const float a0 = __expf(m - mm), a1 = __expf(m1 - mm);
+    const float a0 = __builtin_amdgcn_exp2f(m - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
     const float lt0 = l * a0 + l1 * a1;
     const float lt = lt0 + __shfl_xor(lt0, 32);
     const float inv = (lt > 0.0f && qi < st.n) ? 1.0f / lt : 0.0f;    // padding queries and empty key sets -> 0

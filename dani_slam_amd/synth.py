@@ -199,3 +199,19 @@ def yolo_weights(seed: int = 0, obj_bias: float = -3.0, head_gain: float = 1.0, 
         b[:, 4] += np.float32(obj_bias)
         w[f"model.24.m.{i}.bias"] = b.reshape(-1)
     return w
+
+
+# Class lists for the dynamic-object detector.  The reference reads `coco.names` from the CWD (src/YoloDetect.cpp:12-16;
+# the file is not shipped) -- this is the standard 80-class COCO list of the YOLOv5 release -- and hard-codes its
+# dynamic classes (src/YoloDetect.cpp:17-18, sic "motorbike", "crow").
+COCO_NAMES = ["person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light",
+              "fire hydrant", "stop sign", "parking meter", "bench", "bird", "cat", "dog", "horse", "sheep", "cow",
+              "elephant", "bear", "zebra", "giraffe", "backpack", "umbrella", "handbag", "tie", "suitcase", "frisbee",
+              "skis", "snowboard", "sports ball", "kite", "baseball bat", "baseball glove", "skateboard", "surfboard",
+              "tennis racket", "bottle", "wine glass", "cup", "fork", "knife", "spoon", "bowl", "banana", "apple",
+              "sandwich", "orange", "broccoli", "carrot", "hot dog", "pizza", "donut", "cake", "chair", "couch",
+              "potted plant", "bed", "dining table", "toilet", "tv", "laptop", "mouse", "remote", "keyboard",
+              "cell phone", "microwave", "oven", "toaster", "sink", "refrigerator", "book", "clock", "vase",
+              "scissors", "teddy bear", "hair drier", "toothbrush"]
+DYNAMIC_NAMES = ["person", "car", "motorbike", "bus", "train", "truck", "boat", "bird", "cat",
+                 "dog", "horse", "sheep", "crow", "bear"]
