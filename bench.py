@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="hand the frames over as HOST buffers (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--sequences", type=int, default=1,
                     help="independent image sequences (cameras) processed concurrently per GPU, one host thread each; "
                          "steps are dealt round-robin to them.  2 gives ~+7 % frames/s by filling host-sync gaps, but the "
@@ -117,6 +119,8 @@ def main():
     NSEQ = max(1, args.sequences)
 
     def step(seq=0):
+        if args.host_inputs:
+            return eng.frontend_batch(frames, frames_bgr, nfeatures=NFEATURES, want_desc=True, copy=False, sequence=seq)
         return eng.frontend_batch(None, None, nfeatures=NFEATURES, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()),
                                   shape=(B, H, W), want_desc=True, copy=False, sequence=seq)
 
@@ -186,7 +190,7 @@ def main():
             "metric": "frames/sec SuperPoint+LightGlue+YOLO front-end, 640x480, 1/2/4/8 MI355X",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (frames handed over as HOST buffers: PCIe-inclusive)" if args.host_inputs else ""),
             "config": {"workload": "full front-end (BASELINE config #4 sharded): YOLOv5s boxes -> SuperPoint extract -> "
                                    f"LightGlue vs previous frame, {B} synthetic 640x480 frames per GPU per step resident "
                                    "in HBM, nFeatures=1024, nLevels=1, iniTh=0.015, minTh=0.007, LightGlue 9 layers "

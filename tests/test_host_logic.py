@@ -82,3 +82,32 @@ def test_quadtree_other_aspect_ratios():
         ref = oracle.distribute_octtree(xyr, minX, maxX, minY, maxY, 800)
         idx = frontend.host_distribute_octtree(xyr, minX, maxX, minY, maxY, 800)
         assert np.array_equal(xyr[idx], ref)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """On a machine without an MI355X the engine must refuse to exist (there is no CPU compute path)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(frontend.DaniError) as ei:
+        frontend.Engine(device=0)
+    assert ei.value.code == frontend.DANI_ERR_NO_DEVICE
+    assert "no CPU fallback" in str(ei.value) or "HIP device" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    import ast
+    pkg = os.path.join(ROOT, "dani_slam_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            tree = ast.parse(open(os.path.join(pkg, fn)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                assert not any(n.split(".")[0] == "oracle" for n in names), f"{fn} imports the oracle"
+    for fn in os.listdir(os.path.join(pkg, "csrc")):
+        src = open(os.path.join(pkg, "csrc", fn)).read()
+        assert "#include \"../../oracle" not in src and "liboracle" not in src
