@@ -103,15 +103,19 @@ struct CellRect { int iniX, maxX, iniY, maxY, offX, offY; };
 constexpr int CELL_MAX_DIM = 64;  // a cell is at most 64 x 64 pixels (one lane per column)
 // per-cell threshold + NMS2 (Q4 semantics) + dynamic-box cull -> per-cell slots + counts
 void launch_cell_nms(const float* prob, int PH, int PW, int B, const CellRect* cells, int ncells, float iniTh,
-                     float minTh, const int32_t* boxes, const int32_t* box_offsets, int minBorder, float* slot_xyr,
-                     int32_t* slot_count, int slot_stride, hipStream_t s);
+                     float minTh, const int32_t* boxes, const int32_t* box_offsets, int minBorder, float scale,
+                     float* slot_xyr, int32_t* slot_count, int slot_stride, hipStream_t s);
 // ordered compaction of the per-cell slots -> cand [B][cand_cap][3], cand_count[B]
 void launch_cell_compact(const float* slot_xyr, const int32_t* slot_count, int ncells, int slot_stride, int B,
                          float* cand_xyr, int32_t* cand_count, int cand_cap, hipStream_t s);
 // bilinear sampling (grid_sampler, align_corners=false) + per-channel norm over keypoints (Q7)
+// keypoints [koff[b], koff[b] + nk[b]) of frame b (one pyramid level); max_n = max over b of nk[b]
 void launch_descriptors(const float* desc_nhwc, int Hc, int Wc, int PH, int PW, const float* kxy /*[B][cap][2]*/,
-                        const int32_t* nk /*[B] device*/, int B, int cap, float* sampled /*[B][cap][256]*/,
-                        float* out /*[B][cap][256]*/, hipStream_t s);
+                        const int32_t* koff /*[B] device*/, const int32_t* nk /*[B] device*/, int B, int cap, int max_n,
+                        float* sampled /*[B][cap][256]*/, float* out /*[B][cap][256]*/, hipStream_t s);
+// cv::resize(8UC1, INTER_LINEAR) of B frames (pyramid levels, src/SPextractor.cpp:644)
+void launch_resize_u8c1(const uint8_t* src, int B, int sw, int sh, int sstride, size_t sframe, uint8_t* dst, int dw, int dh,
+                        hipStream_t s);
 void launch_copy_layer_dense(const ActDesc& a, int b, float* out_dense, hipStream_t s);
 
 // ---- LightGlue kernels (lg_kernels.hip) ------------------------------------------------------------

@@ -45,17 +45,26 @@ struct Context {
   hipStream_t stream2 = nullptr;   // YOLO (concurrent with the SuperPoint conv stack) and overlapped D2H copies
   hipEvent_t ev_desc = nullptr, ev_y0 = nullptr, ev_y1 = nullptr;
   int W = 0, H = 0, B = 0;  // shapes the buffers are built for
-  ActDesc act[12];          // output of layer i (layers 1,3,5: pooled)
-  float* prob = nullptr;
-  float* desc_nhwc = nullptr;
-  float* desc_nchw = nullptr;
-  std::vector<CellRect> cells;
-  CellRect* d_cells = nullptr;
-  int slot_stride = 0;
-  float* slot_xyr = nullptr;
-  int32_t* slot_count = nullptr;
-  float* cand = nullptr;
-  int32_t* cand_count = nullptr;
+  int nlevels = 0;
+  float scale_factor = 0.0f;
+  struct Level {              // one pyramid level (ComputePyramid, src/SPextractor.cpp:631-656)
+    int W = 0, H = 0;
+    ActDesc act[12];          // output of layer i (layers 1,3,5: pooled)
+    float* prob = nullptr;
+    float* desc_nhwc = nullptr;
+    float* desc_nchw = nullptr;
+    std::vector<CellRect> cells;
+    CellRect* d_cells = nullptr;
+    int slot_stride = 0;
+    float* slot_xyr = nullptr;
+    int32_t* slot_count = nullptr;
+    float* cand = nullptr;
+    int32_t* cand_count = nullptr;
+    float* h_cand = nullptr;          // pinned
+    int32_t* h_cand_count = nullptr;  // pinned
+    uint8_t* d_level_img = nullptr;   // level > 0: this level's image [B][H][W] (resized from level - 1)
+  };
+  std::vector<Level> lv;
   int32_t* d_boxes = nullptr;
   int32_t* d_box_offsets = nullptr;
   int box_cap = 0;
@@ -70,9 +79,7 @@ struct Context {
   float* d_descout = nullptr;
   int kcap = 0;
   // pinned host staging
-  float* h_cand = nullptr;
-  int32_t* h_cand_count = nullptr;
-  float* h_kxy = nullptr;  // [B][kcap][2] followed by nk[B]
+  float* h_kxy = nullptr;  // [B][kcap][2] followed by per-level (offset, count) ints [nlevels][2][B]
   int32_t* h_boxes = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t lev[13] = {};
@@ -233,74 +240,97 @@ void free_buffers(Context* c) {
   for (void* p : c->host_allocs) (void)hipHostFree(p);
   c->dev_allocs.clear();
   c->host_allocs.clear();
+  c->lv.clear();
   c->W = c->H = c->B = 0;
+  c->nlevels = 0;
 }
 
-// (re)build the per-context buffers for image size W x H and batch B
-int ensure_shapes(dani_engine* e, Context* c, int W, int H, int B, int kcap) {
-  if (c->W == W && c->H == H && c->B >= B && c->kcap >= kcap) return 0;
+// pyramid level sizes: cvRound(dim * mvInvScaleFactor[level]) (src/SPextractor.cpp:635-636)
+void level_dims(int W, int H, float scaleFactor, int nlevels, std::vector<int>& lw, std::vector<int>& lh, std::vector<float>& scales) {
+  std::vector<int> per;
+  features_per_level(1000, scaleFactor, nlevels, per, scales);
+  lw.assign(nlevels, W); lh.assign(nlevels, H);
+  for (int l = 1; l < nlevels; l++) {
+    const float inv = 1.0f / scales[l];
+    lw[l] = (int)lrintf((float)W * inv);
+    lh[l] = (int)lrintf((float)H * inv);
+  }
+}
+
+// (re)build the per-context buffers for image size W x H, batch B and the pyramid (nlevels, scaleFactor)
+int ensure_shapes(dani_engine* e, Context* c, int W, int H, int B, int kcap, int nlevels, float scaleFactor) {
+  if (c->W == W && c->H == H && c->B >= B && c->kcap >= kcap && c->nlevels == nlevels && c->scale_factor == scaleFactor) return 0;
   HIP_TRY(e, hipStreamSynchronize(c->stream));
   free_buffers(c);
-  const int dims[12][2] = {{H, W}, {H / 2, W / 2}, {H / 2, W / 2}, {H / 4, W / 4}, {H / 4, W / 4}, {H / 8, W / 8},
-                           {H / 8, W / 8}, {H / 8, W / 8}, {H / 8, W / 8}, {H / 8, W / 8}, {H / 8, W / 8}, {H / 8, W / 8}};
-  for (int i = 0; i < 12; i++) {
-    act_shape(c->act[i], kSp[i].cout, dims[i][0], dims[i][1]);
-    int rc = dev_alloc(e, c, (void**)&c->act[i].p, c->act[i].bytes(B), true);  // zero borders, once
-    if (rc) return rc;
-  }
-  const int Hc = H / 8, Wc = W / 8, PH = Hc * 8, PW = Wc * 8;
+  std::vector<int> lw, lh; std::vector<float> scales;
+  level_dims(W, H, scaleFactor, nlevels, lw, lh, scales);
+  c->lv.resize(nlevels);
   int rc;
-  if ((rc = dev_alloc(e, c, (void**)&c->prob, (size_t)B * PH * PW * 4, false))) return rc;
-  if ((rc = dev_alloc(e, c, (void**)&c->desc_nhwc, (size_t)B * Hc * Wc * 256 * 4, false))) return rc;
-  if ((rc = dev_alloc(e, c, (void**)&c->desc_nchw, (size_t)B * Hc * Wc * 256 * 4, false))) return rc;
-  cell_grid(W, H, c->cells);
-  int max_area = 1;
-  for (const CellRect& r : c->cells) {
-    const int w = r.maxX - r.iniX, h = r.maxY - r.iniY;
-    if (w > CELL_MAX_DIM || h > CELL_MAX_DIM || w <= 0 || h <= 0)
-      return fail(e, DANI_ERR_UNSUPPORTED, "cell %dx%d exceeds the %d-pixel cell kernel limit", w, h, CELL_MAX_DIM);
-    max_area = std::max(max_area, w * h);
+  for (int l = 0; l < nlevels; l++) {
+    Context::Level& L = c->lv[l];
+    L.W = lw[l]; L.H = lh[l];
+    const int h = L.H, w = L.W;
+    if (w < 80 || h < 80) return fail(e, DANI_ERR_UNSUPPORTED, "pyramid level %d is %dx%d: smaller than 80x80", l, w, h);
+    const int dims[12][2] = {{h, w}, {h / 2, w / 2}, {h / 2, w / 2}, {h / 4, w / 4}, {h / 4, w / 4}, {h / 8, w / 8},
+                             {h / 8, w / 8}, {h / 8, w / 8}, {h / 8, w / 8}, {h / 8, w / 8}, {h / 8, w / 8}, {h / 8, w / 8}};
+    for (int i = 0; i < 12; i++) {
+      act_shape(L.act[i], kSp[i].cout, dims[i][0], dims[i][1]);
+      if ((rc = dev_alloc(e, c, (void**)&L.act[i].p, L.act[i].bytes(B), true))) return rc;  // zero borders, once
+    }
+    const int Hc = h / 8, Wc = w / 8, PH = Hc * 8, PW = Wc * 8;
+    if ((rc = dev_alloc(e, c, (void**)&L.prob, (size_t)B * PH * PW * 4, false))) return rc;
+    if ((rc = dev_alloc(e, c, (void**)&L.desc_nhwc, (size_t)B * Hc * Wc * 256 * 4, false))) return rc;
+    if ((rc = dev_alloc(e, c, (void**)&L.desc_nchw, (size_t)B * Hc * Wc * 256 * 4, false))) return rc;
+    cell_grid(w, h, L.cells);
+    int max_area = 1;
+    for (const CellRect& r : L.cells) {
+      const int cw = r.maxX - r.iniX, chh = r.maxY - r.iniY;
+      if (cw > CELL_MAX_DIM || chh > CELL_MAX_DIM || cw <= 0 || chh <= 0)
+        return fail(e, DANI_ERR_UNSUPPORTED, "cell %dx%d exceeds the %d-pixel cell kernel limit", cw, chh, CELL_MAX_DIM);
+      max_area = std::max(max_area, cw * chh);
+    }
+    L.slot_stride = max_area;
+    const int nc = std::max<int>(1, (int)L.cells.size());
+    if ((rc = dev_alloc(e, c, (void**)&L.d_cells, sizeof(CellRect) * nc, false))) return rc;
+    if (!L.cells.empty())
+      HIP_TRY(e, hipMemcpyAsync(L.d_cells, L.cells.data(), sizeof(CellRect) * L.cells.size(), hipMemcpyHostToDevice, c->stream));
+    if ((rc = dev_alloc(e, c, (void**)&L.slot_xyr, (size_t)B * nc * L.slot_stride * 3 * 4, false))) return rc;
+    if ((rc = dev_alloc(e, c, (void**)&L.slot_count, (size_t)B * nc * 4, true))) return rc;
+    if ((rc = dev_alloc(e, c, (void**)&L.cand, (size_t)B * CAND_CAP * 3 * 4, false))) return rc;
+    if ((rc = dev_alloc(e, c, (void**)&L.cand_count, (size_t)B * 4, true))) return rc;
+    if ((rc = host_alloc(e, c, (void**)&L.h_cand, (size_t)B * CAND_CAP * 3 * 4))) return rc;
+    if ((rc = host_alloc(e, c, (void**)&L.h_cand_count, (size_t)B * 4))) return rc;
+    if (l > 0 && (rc = dev_alloc(e, c, (void**)&L.d_level_img, (size_t)B * h * w, false))) return rc;
   }
-  c->slot_stride = max_area;
-  const int nc = std::max<int>(1, (int)c->cells.size());
-  if ((rc = dev_alloc(e, c, (void**)&c->d_cells, sizeof(CellRect) * nc, false))) return rc;
-  if (!c->cells.empty())
-    HIP_TRY(e, hipMemcpyAsync(c->d_cells, c->cells.data(), sizeof(CellRect) * c->cells.size(), hipMemcpyHostToDevice, c->stream));
-  if ((rc = dev_alloc(e, c, (void**)&c->slot_xyr, (size_t)B * nc * c->slot_stride * 3 * 4, false))) return rc;
-  if ((rc = dev_alloc(e, c, (void**)&c->slot_count, (size_t)B * nc * 4, true))) return rc;
-  if ((rc = dev_alloc(e, c, (void**)&c->cand, (size_t)B * CAND_CAP * 3 * 4, false))) return rc;
-  if ((rc = dev_alloc(e, c, (void**)&c->cand_count, (size_t)B * 4, true))) return rc;
   c->box_cap = 1024;
   if ((rc = dev_alloc(e, c, (void**)&c->d_boxes, (size_t)(c->box_cap * 4 + B + 1) * 4, true))) return rc;
   c->d_box_offsets = c->d_boxes + c->box_cap * 4;
   c->d_img_bytes = (size_t)B * H * round_up(W, 64) * 2;
   if ((rc = dev_alloc(e, c, (void**)&c->d_img, c->d_img_bytes, false))) return rc;
   c->kcap = kcap;
+  const size_t nints = (size_t)nlevels * 2 * B;
   // feature slabs: slot 0 holds the last frame of the previous dani_frontend_batch call (sequence matching),
-  // slots 1..B the current frames; d_kxy / d_descout point at slot 1
-  if ((rc = dev_alloc(e, c, (void**)&c->d_kxy_all, ((size_t)(B + 1) * kcap * 2 + B) * 4, true))) return rc;
+  // slots 1..B the current frames; d_kxy / d_descout point at slot 1; the per-level (offset, count) ints follow
+  if ((rc = dev_alloc(e, c, (void**)&c->d_kxy_all, ((size_t)(B + 1) * kcap * 2 + nints) * 4, true))) return rc;
   c->d_kxy = c->d_kxy_all + (size_t)kcap * 2;
   c->d_nk = reinterpret_cast<int32_t*>(c->d_kxy + (size_t)B * kcap * 2);
   if ((rc = dev_alloc(e, c, (void**)&c->d_sampled, ((size_t)B * kcap * 256 + B * 256) * 4, false))) return rc;
   if ((rc = dev_alloc(e, c, (void**)&c->d_desc_all, (size_t)(B + 1) * kcap * 256 * 4, true))) return rc;
   c->d_descout = c->d_desc_all + (size_t)kcap * 256;
   c->prev_n = 0;
-  if ((rc = host_alloc(e, c, (void**)&c->h_cand, (size_t)B * CAND_CAP * 3 * 4))) return rc;
-  if ((rc = host_alloc(e, c, (void**)&c->h_cand_count, (size_t)B * 4))) return rc;
-  if ((rc = host_alloc(e, c, (void**)&c->h_kxy, ((size_t)B * kcap * 2 + B) * 4))) return rc;
+  if ((rc = host_alloc(e, c, (void**)&c->h_kxy, ((size_t)B * kcap * 2 + nints) * 4))) return rc;
   if ((rc = host_alloc(e, c, (void**)&c->h_boxes, (size_t)(c->box_cap * 4 + B + 1) * 4))) return rc;
   HIP_TRY(e, hipStreamSynchronize(c->stream));
-  c->W = W; c->H = H; c->B = B;
+  c->W = W; c->H = H; c->B = B; c->nlevels = nlevels; c->scale_factor = scaleFactor;
   return 0;
 }
 
 int check_params(dani_engine* e, int W, int H, const dani_sp_params* p) {
   if (!p) return fail(e, DANI_ERR_INVALID, "null params");
-  if (p->nlevels != 1)
-    return fail(e, DANI_ERR_UNSUPPORTED, "nlevels=%d: only nlevels=1 is implemented (the reference's tuned YAMLs, "
-                "Examples/RGB-D/TUM3.yaml:42-55, use 1)", p->nlevels);
-  if (W % 8 || H % 8 || W < 80 || H < 80)
-    return fail(e, DANI_ERR_UNSUPPORTED, "image %dx%d: width and height must be multiples of 8 and >= 80", W, H);
+  if (p->nlevels < 1 || p->nlevels > 16) return fail(e, DANI_ERR_INVALID, "nlevels=%d outside [1, 16]", p->nlevels);
+  if (p->nlevels > 1 && !(p->scale_factor > 1.0f)) return fail(e, DANI_ERR_INVALID, "scaleFactor must be > 1 for a pyramid");
+  if (W < 80 || H < 80)
+    return fail(e, DANI_ERR_UNSUPPORTED, "image %dx%d: width and height must be >= 80", W, H);
   if (W > e->cfg.max_width || H > e->cfg.max_height)
     return fail(e, DANI_ERR_INVALID, "image %dx%d exceeds the engine's configured maximum %dx%d", W, H, e->cfg.max_width, e->cfg.max_height);
   if (p->nfeatures <= 0 || !(p->ini_th >= 0.0f) || !(p->min_th >= 0.0f)) return fail(e, DANI_ERR_INVALID, "bad extractor params");
@@ -469,39 +499,52 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   t_last_ctx = c;
   std::vector<int> per_level; std::vector<float> scales;
   features_per_level(p->nfeatures, p->scale_factor, p->nlevels, per_level, scales);
-  const int N = per_level[0];
-  const int kcap = N + 8;  // DistributeOctTree can exceed N by at most 3
-  if ((rc = ensure_shapes(e, c, W, H, e->cfg.max_batch, std::max(kcap, c->kcap)))) return rc;
+  const int NL = p->nlevels;
+  int kcap = 8;
+  for (int l = 0; l < NL; l++) kcap += per_level[l] + 3;  // DistributeOctTree can exceed N by at most 3 per level
+  if ((rc = ensure_shapes(e, c, W, H, e->cfg.max_batch, std::max(kcap, c->kcap), NL, p->scale_factor))) return rc;
   hipStream_t s = c->stream;
-  const int Hc = H / 8, Wc = W / 8, PH = Hc * 8, PW = Wc * 8;
-  const int ncells = (int)c->cells.size();
+  const int MB = e->cfg.max_batch;
 
   const bool prof = e->profiling;
   const int phase = t_sp_phase;
   if (phase != 2) {
-  // ---- inputs
-  const uint8_t* dimg = imgs;
-  const size_t fbytes = (size_t)H * stride;
-  if (!imgs_on_device) {
-    if (fbytes * B > c->d_img_bytes) return fail(e, DANI_ERR_INVALID, "stride %d too large for the staging buffer", stride);
-    HIP_TRY(e, hipMemcpyAsync(c->d_img, imgs, fbytes * B, hipMemcpyHostToDevice, s));
-    dimg = c->d_img;
-  }
-  // ---- network
-  HIP_TRY(e, hipEventRecord(c->ev[0], s));
-  if (prof) HIP_TRY(e, hipEventRecord(c->lev[0], s));
-  launch_conv1a(dimg, B, H, W, stride, fbytes, e->w1a, e->b1a, c->act[0], s);
-  if (prof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
-  const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
-  for (int i = 1; i < 12; i++) {
-    launch_conv_mfma(e->plan[i], c->act[src_of[i]], c->act[i], B, s);
-    if (prof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
-  }
-  HIP_TRY(e, hipEventRecord(c->ev[1], s));
-  launch_softmax_d2s(c->act[9], c->prob, B, s);
-  launch_desc_norm(c->act[11], c->desc_nhwc, c->desc_nchw, B, s);
-  HIP_TRY(e, hipGetLastError());
-  if (phase == 1) return DANI_OK;   // network enqueued; the caller continues with phase 2 once the boxes are known
+    // ---- inputs
+    const uint8_t* dimg = imgs;
+    const size_t fbytes = (size_t)H * stride;
+    if (!imgs_on_device) {
+      if (fbytes * B > c->d_img_bytes) return fail(e, DANI_ERR_INVALID, "stride %d too large for the staging buffer", stride);
+      HIP_TRY(e, hipMemcpyAsync(c->d_img, imgs, fbytes * B, hipMemcpyHostToDevice, s));
+      dimg = c->d_img;
+    }
+    // ---- pyramid + network, level by level
+    HIP_TRY(e, hipEventRecord(c->ev[0], s));
+    for (int l = 0; l < NL; l++) {
+      Context::Level& L = c->lv[l];
+      const uint8_t* limg = dimg; int lstride = stride; size_t lframe = fbytes;
+      if (l > 0) {
+        const Context::Level& P = c->lv[l - 1];
+        const uint8_t* src = (l == 1) ? dimg : P.d_level_img;
+        const int sstride = (l == 1) ? stride : P.W;
+        const size_t sframe = (l == 1) ? fbytes : (size_t)P.W * P.H;
+        launch_resize_u8c1(src, B, P.W, P.H, sstride, sframe, L.d_level_img, L.W, L.H, s);
+        limg = L.d_level_img; lstride = L.W; lframe = (size_t)L.W * L.H;
+      }
+      const bool lprof = prof && l == 0;
+      if (lprof) HIP_TRY(e, hipEventRecord(c->lev[0], s));
+      launch_conv1a(limg, B, L.H, L.W, lstride, lframe, e->w1a, e->b1a, L.act[0], s);
+      if (lprof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
+      const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
+      for (int i = 1; i < 12; i++) {
+        launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, s);
+        if (lprof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
+      }
+      if (l == NL - 1) HIP_TRY(e, hipEventRecord(c->ev[1], s));
+      launch_softmax_d2s(L.act[9], L.prob, B, s);
+      launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, s);
+    }
+    HIP_TRY(e, hipGetLastError());
+    if (phase == 1) return DANI_OK;   // network enqueued; the caller continues with phase 2 once the boxes are known
   }
   int nboxes_total = 0;
   if (boxes && box_offsets) nboxes_total = box_offsets[B];
@@ -514,66 +557,91 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
     if (nboxes_total) HIP_TRY(e, hipMemcpyAsync(c->d_boxes, hb, (size_t)nboxes_total * 16, hipMemcpyHostToDevice, s));
     HIP_TRY(e, hipMemcpyAsync(c->d_box_offsets, ho, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
   }
-
-  if (ncells > 0) {
-    launch_cell_nms(c->prob, PH, PW, B, c->d_cells, ncells, p->ini_th, p->min_th, c->d_boxes, c->d_box_offsets,
-                    19 - 3, c->slot_xyr, c->slot_count, c->slot_stride, s);
-    launch_cell_compact(c->slot_xyr, c->slot_count, ncells, c->slot_stride, B, c->cand, c->cand_count, CAND_CAP, s);
+  for (int l = 0; l < NL; l++) {
+    Context::Level& L = c->lv[l];
+    const int PH = (L.H / 8) * 8, PW = (L.W / 8) * 8, ncells = (int)L.cells.size();
+    if (ncells > 0) {
+      launch_cell_nms(L.prob, PH, PW, B, L.d_cells, ncells, p->ini_th, p->min_th, c->d_boxes, c->d_box_offsets,
+                      19 - 3, scales[l], L.slot_xyr, L.slot_count, L.slot_stride, s);
+      launch_cell_compact(L.slot_xyr, L.slot_count, ncells, L.slot_stride, B, L.cand, L.cand_count, CAND_CAP, s);
+      HIP_TRY(e, hipMemcpyAsync(L.h_cand_count, L.cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    }
   }
   HIP_TRY(e, hipEventRecord(c->ev[2], s));
   HIP_TRY(e, hipGetLastError());
-  HIP_TRY(e, hipMemcpyAsync(c->h_cand_count, c->cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));
-  for (int b = 0; b < B; b++) {
-    int nc = ncells > 0 ? c->h_cand_count[b] : 0;
-    if (nc > CAND_CAP) return fail(e, DANI_ERR_CAPACITY, "frame %d has %d candidates (> %d)", b, nc, CAND_CAP);
-    c->h_cand_count[b] = nc;
-    if (nc) HIP_TRY(e, hipMemcpyAsync(c->h_cand + (size_t)b * CAND_CAP * 3, c->cand + (size_t)b * CAND_CAP * 3, (size_t)nc * 12, hipMemcpyDeviceToHost, s));
+  for (int l = 0; l < NL; l++) {
+    Context::Level& L = c->lv[l];
+    for (int b = 0; b < B; b++) {
+      int nc = L.cells.empty() ? 0 : L.h_cand_count[b];
+      if (nc > CAND_CAP) return fail(e, DANI_ERR_CAPACITY, "frame %d level %d has %d candidates (> %d)", b, l, nc, CAND_CAP);
+      L.h_cand_count[b] = nc;
+      if (nc) HIP_TRY(e, hipMemcpyAsync(L.h_cand + (size_t)b * CAND_CAP * 3, L.cand + (size_t)b * CAND_CAP * 3, (size_t)nc * 12, hipMemcpyDeviceToHost, s));
+    }
   }
   HIP_TRY(e, hipStreamSynchronize(s));
 
-  // ---- host: quadtree, keypoint assembly (SPextractor.cpp:359-376, :164-216)
+  // ---- host: quadtree per (frame, level), keypoint assembly (SPextractor.cpp:359-376, :164-216)
   const auto t0 = std::chrono::steady_clock::now();
-  const int minBorderX = 19 - 3, minBorderY = minBorderX, maxBorderX = W - 19 + 3, maxBorderY = H - 19 + 3;
-  const int scaledPatchSize = (int)(31 * scales[0]);
-  int32_t* h_nk = reinterpret_cast<int32_t*>(c->h_kxy + (size_t)e->cfg.max_batch * c->kcap * 2);
+  const int minBorderX = 19 - 3, minBorderY = minBorderX;
+  int32_t* h_lv = reinterpret_cast<int32_t*>(c->h_kxy + (size_t)MB * c->kcap * 2);   // [level][0: offset, 1: count][MB]
   int status = DANI_OK;
-  // the quadtree of each frame is independent: one host thread per frame (it is ~90 us of serial work per frame)
-  std::vector<std::vector<int>> sels(B);
-  host_pool().run(B, [&](int b) {
-    const HostKey* keys = reinterpret_cast<const HostKey*>(c->h_cand + (size_t)b * CAND_CAP * 3);
-    distribute_octtree(keys, c->h_cand_count[b], minBorderX, maxBorderX, minBorderY, maxBorderY, N, sels[b]);
+  std::vector<std::vector<int>> sels((size_t)B * NL);
+  host_pool().run(B * NL, [&](int t) {
+    const int b = t / NL, l = t % NL;
+    const Context::Level& L = c->lv[l];
+    const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+    distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[l], sels[t]);
   });
   for (int b = 0; b < B; b++) {
-    const HostKey* keys = reinterpret_cast<const HostKey*>(c->h_cand + (size_t)b * CAND_CAP * 3);
-    const std::vector<int>& sel = sels[b];
-    const int n = (int)sel.size();
+    int n = 0;
+    for (int l = 0; l < NL; l++) n += (int)sels[(size_t)b * NL + l].size();
     n_out[b] = n;
-    if (n > cap || n > c->kcap) { status = DANI_ERR_CAPACITY; h_nk[b] = 0; continue; }
-    h_nk[b] = n;
+    const bool fits = n <= cap && n <= c->kcap;
+    if (!fits) status = DANI_ERR_CAPACITY;
     float* kx = c->h_kxy + (size_t)b * c->kcap * 2;
-    for (int i = 0; i < n; i++) { kx[2 * i] = keys[sel[i]].x + minBorderX; kx[2 * i + 1] = keys[sel[i]].y + minBorderY; }
-    // mono / stereo partition of the keypoints only (descriptor rows keep the pre-partition order)
-    int monoIndex = 0, stereoIndex = n - 1;
     float* ok = kpts_xy + (size_t)b * cap * 2;
     float* orr = resp + (size_t)b * cap;
+    // the mono / stereo partition runs over the levels in order (operator(), :175-213); descriptor rows keep the
+    // pre-partition order
+    int monoIndex = 0, stereoIndex = n - 1, off = 0;
     const int l0 = lapping ? lapping[0] : 0, l1 = lapping ? lapping[1] : 0;
-    for (int i = 0; i < n; i++) {
-      const float x = kx[2 * i], y = kx[2 * i + 1];
-      const int dst = (x >= (float)l0 && x <= (float)l1) ? stereoIndex-- : monoIndex++;
-      ok[2 * dst] = x; ok[2 * dst + 1] = y; orr[dst] = keys[sel[i]].r;
+    for (int l = 0; l < NL; l++) {
+      const Context::Level& L = c->lv[l];
+      const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+      const std::vector<int>& sel = sels[(size_t)b * NL + l];
+      const int nl = fits ? (int)sel.size() : 0;
+      h_lv[(l * 2 + 0) * MB + b] = off;
+      h_lv[(l * 2 + 1) * MB + b] = nl;
+      const int scaledPatchSize = (int)(31 * scales[l]);
+      for (int i = 0; i < nl; i++) {
+        const float x = keys[sel[i]].x + minBorderX, y = keys[sel[i]].y + minBorderY;   // level coordinates (:369-370)
+        kx[2 * (off + i)] = x; kx[2 * (off + i) + 1] = y;
+        const float fx = l ? x * scales[l] : x, fy = l ? y * scales[l] : y;              // keypoint->pt *= scale (:190-192)
+        const int dst = (fx >= (float)l0 && fx <= (float)l1) ? stereoIndex-- : monoIndex++;
+        ok[2 * dst] = fx; ok[2 * dst + 1] = fy; orr[dst] = keys[sel[i]].r;
+        if (octave) octave[(size_t)b * cap + dst] = l;
+        if (size) size[(size_t)b * cap + dst] = (float)scaledPatchSize;
+      }
+      off += nl;
     }
-    if (octave) for (int i = 0; i < n; i++) octave[(size_t)b * cap + i] = 0;
-    if (size) for (int i = 0; i < n; i++) size[(size_t)b * cap + i] = (float)scaledPatchSize;
     if (mono_index) mono_index[b] = monoIndex;
   }
   c->ms[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (status != DANI_OK) return fail(e, status, "output capacity %d too small", cap);
 
-  // ---- descriptors
-  HIP_TRY(e, hipMemcpyAsync(c->d_kxy, c->h_kxy, ((size_t)e->cfg.max_batch * c->kcap * 2 + B) * 4, hipMemcpyHostToDevice, s));
+  // ---- descriptors: each level samples its own map and is normalised over its own keypoints (Q7)
+  HIP_TRY(e, hipMemcpyAsync(c->d_kxy, c->h_kxy, ((size_t)MB * c->kcap * 2 + (size_t)NL * 2 * MB) * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(e, hipEventRecord(c->ev[3], s));
-  launch_descriptors(c->desc_nhwc, Hc, Wc, PH, PW, c->d_kxy, c->d_nk, B, c->kcap, c->d_sampled, c->d_descout, s);
+  for (int l = 0; l < NL; l++) {
+    const Context::Level& L = c->lv[l];
+    const int Hc = L.H / 8, Wc = L.W / 8;
+    int maxn = 0;
+    for (int b = 0; b < B; b++) maxn = std::max(maxn, h_lv[(l * 2 + 1) * MB + b]);
+    if (maxn == 0) continue;
+    launch_descriptors(L.desc_nhwc, Hc, Wc, Hc * 8, Wc * 8, c->d_kxy, c->d_nk + (size_t)(l * 2 + 0) * MB, c->d_nk + (size_t)(l * 2 + 1) * MB, B, c->kcap,
+                       maxn, c->d_sampled, c->d_descout, s);
+  }
   HIP_TRY(e, hipEventRecord(c->ev[4], s));
   if (desc) {   // descriptor read-back on the second stream so that it can run under the next stage's kernels
     HIP_TRY(e, hipEventRecord(c->ev_desc, s));
@@ -607,13 +675,17 @@ int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* desc_map,
   Context* c = t_last_ctx;
   if (!e || !c || b < 0 || b >= c->B) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
   HIP_TRY(e, hipSetDevice(e->device));
-  const int Hc = c->H / 8, Wc = c->W / 8;
-  if (prob) HIP_TRY(e, hipMemcpy(prob, c->prob + (size_t)b * Hc * 8 * Wc * 8, (size_t)Hc * 8 * Wc * 8 * 4, hipMemcpyDeviceToHost));
-  if (desc_map) HIP_TRY(e, hipMemcpy(desc_map, c->desc_nchw + (size_t)b * 256 * Hc * Wc, (size_t)256 * Hc * Wc * 4, hipMemcpyDeviceToHost));
-  if (n_cand) *n_cand = c->h_cand_count[b];
+  if (c->lv.empty()) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
+  const char* lvl_env = getenv("DANI_DEBUG_LEVEL");   // tests: inspect another pyramid level
+  const int dl = lvl_env ? std::min(std::max(atoi(lvl_env), 0), (int)c->lv.size() - 1) : 0;
+  const Context::Level& L = c->lv[dl];
+  const int Hc = L.H / 8, Wc = L.W / 8;
+  if (prob) HIP_TRY(e, hipMemcpy(prob, L.prob + (size_t)b * Hc * 8 * Wc * 8, (size_t)Hc * 8 * Wc * 8 * 4, hipMemcpyDeviceToHost));
+  if (desc_map) HIP_TRY(e, hipMemcpy(desc_map, L.desc_nchw + (size_t)b * 256 * Hc * Wc, (size_t)256 * Hc * Wc * 4, hipMemcpyDeviceToHost));
+  if (n_cand) *n_cand = L.h_cand_count[b];
   if (cand_xyr) {
-    const int n = std::min(c->h_cand_count[b], cand_cap);
-    memcpy(cand_xyr, c->h_cand + (size_t)b * CAND_CAP * 3, (size_t)n * 12);
+    const int n = std::min(L.h_cand_count[b], cand_cap);
+    memcpy(cand_xyr, L.h_cand + (size_t)b * CAND_CAP * 3, (size_t)n * 12);
   }
   return DANI_OK;
 }
@@ -621,7 +693,8 @@ int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* desc_map,
 int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, int64_t count) {
   Context* c = t_last_ctx;
   if (!e || !c || b < 0 || b >= c->B || layer < 0 || layer >= 12 || !out) return fail(e, DANI_ERR_INVALID, "bad argument");
-  const ActDesc& a = c->act[layer];
+  if (c->lv.empty()) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
+  const ActDesc& a = c->lv[0].act[layer];
   const size_t need = (size_t)a.C * a.H * a.W;
   if ((size_t)count < need) return fail(e, DANI_ERR_CAPACITY, "layer %d needs %zu floats", layer, need);
   HIP_TRY(e, hipSetDevice(e->device));

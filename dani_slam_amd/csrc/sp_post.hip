@@ -128,8 +128,8 @@ constexpr int CELL_MAX_W = 64, CELL_MAX_H = 64;  // one lane per cell column
 
 __global__ __launch_bounds__(64) void cell_nms_kernel(const float* prob, int PH, int PW, const CellRect* cells,
                                                       int ncells, float iniTh, float minTh, const int32_t* boxes,
-                                                      const int32_t* box_offsets, int minBorder, float* slot_xyr,
-                                                      int32_t* slot_count, int slot_stride) {
+                                                      const int32_t* box_offsets, int minBorder, float scale,
+                                                      float* slot_xyr, int32_t* slot_count, int slot_stride) {
   __shared__ float conf[CELL_MAX_W * CELL_MAX_H];
   __shared__ int sbox[256 * 4];   // this frame's dynamic boxes (first 256; the rest are read from global memory)
   __shared__ uint8_t grid[(CELL_MAX_H + 2 * NMS_D) * (CELL_MAX_W + 2 * NMS_D)];
@@ -185,28 +185,40 @@ __global__ __launch_bounds__(64) void cell_nms_kernel(const float* prob, int PH,
           __syncthreads();
         }
       }
-      // emission in row-major order + dynamic-box cull (scale 1: one exact containment test)
+      // emission in row-major order + dynamic-box cull.  The reference (SPextractor.cpp:314-352) maps ALL accumulated
+      // points p -> (p + border) * scale, erases those inside a box, and maps back p * (1/scale) - border after
+      // EVERY non-skipped cell, i.e. a point emitted by cell ci goes through (ncells - ci) round trips.  At scale 1
+      // the round trip is exact (one test suffices); otherwise the f32 drift and the per-trip test are replayed here
+      // literally (quirk Q6) -- the drifted coordinates are what the quadtree and the keypoints see.
       emitted = 0;
+      const float fb = (float)minBorder, sinv = 1.0f / scale;
+      const int trips = (scale == 1.0f) ? 1 : (ncells - cell);
       for (int y = 0; y < h; y++) {
         bool keep = lane < w && grid[(y + NMS_D) * gw + lane + NMS_D] == 2;
-        const int px = lane + c.offX + minBorder, py = y + c.offY + minBorder;
+        float fx = (float)(lane + c.offX), fy = (float)(y + c.offY);
         if (__ballot(keep)) {
-          bool inside = false;
-          for (int bi = 0; bi < nbl; bi++) {               // uniform trip count, LDS broadcast reads
-            const int bx = sbox[4 * bi], by = sbox[4 * bi + 1], bw = sbox[4 * bi + 2], bh = sbox[4 * bi + 3];
-            inside |= (bx <= px && px < bx + bw && by <= py && py < by + bh);
+          for (int t = 0; t < trips; t++) {
+            float sx = fx + fb, sy = fy + fb;
+            sx *= scale; sy *= scale;
+            const int px = __float2int_rn(sx), py = __float2int_rn(sy);   // Rect::contains(Point2f): saturate_cast<int>
+            bool inside = false;
+            for (int bi = 0; bi < nbl; bi++) {               // uniform trip count, LDS broadcast reads
+              const int bx = sbox[4 * bi], by = sbox[4 * bi + 1], bw = sbox[4 * bi + 2], bh = sbox[4 * bi + 3];
+              inside |= (bx <= px && px < bx + bw && by <= py && py < by + bh);
+            }
+            for (int bi = nb0 + nbl; bi < nb1; bi++) {
+              const int bx = boxes[4 * bi], by = boxes[4 * bi + 1], bw = boxes[4 * bi + 2], bh = boxes[4 * bi + 3];
+              inside |= (bx <= px && px < bx + bw && by <= py && py < by + bh);
+            }
+            keep = keep && !inside;
+            if (scale != 1.0f) { sx *= sinv; sy *= sinv; fx = sx - fb; fy = sy - fb; }
           }
-          for (int bi = nb0 + nbl; bi < nb1; bi++) {
-            const int bx = boxes[4 * bi], by = boxes[4 * bi + 1], bw = boxes[4 * bi + 2], bh = boxes[4 * bi + 3];
-            inside |= (bx <= px && px < bx + bw && by <= py && py < by + bh);
-          }
-          keep = keep && !inside;
         }
         const unsigned long long km = __ballot(keep);
         if (keep) {
           const int pos = emitted + __popcll(km & ((1ull << lane) - 1));
-          slot[3 * pos + 0] = (float)(lane + c.offX);
-          slot[3 * pos + 1] = (float)(y + c.offY);
+          slot[3 * pos + 0] = fx;
+          slot[3 * pos + 1] = fy;
           slot[3 * pos + 2] = conf[y * w + lane];
         }
         emitted += __popcll(km);
@@ -220,10 +232,10 @@ __global__ __launch_bounds__(64) void cell_nms_kernel(const float* prob, int PH,
 }
 
 void launch_cell_nms(const float* prob, int PH, int PW, int B, const CellRect* cells, int ncells, float iniTh,
-                     float minTh, const int32_t* boxes, const int32_t* box_offsets, int minBorder, float* slot_xyr,
-                     int32_t* slot_count, int slot_stride, hipStream_t s) {
+                     float minTh, const int32_t* boxes, const int32_t* box_offsets, int minBorder, float scale,
+                     float* slot_xyr, int32_t* slot_count, int slot_stride, hipStream_t s) {
   hipLaunchKernelGGL(cell_nms_kernel, dim3(ncells, B), dim3(64), 0, s, prob, PH, PW, cells, ncells, iniTh, minTh,
-                     boxes, box_offsets, minBorder, slot_xyr, slot_count, slot_stride);
+                     boxes, box_offsets, minBorder, scale, slot_xyr, slot_count, slot_stride);
 }
 
 // ordered compaction: cell c of frame b copies its slot to cand[b][prefix(c) ...]
@@ -257,10 +269,11 @@ void launch_cell_compact(const float* slot_xyr, const int32_t* slot_count, int n
 // frame's keypoints (quirk Q7), output [n][256].
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void desc_sample_kernel(const float* desc_nhwc, int Hc, int Wc, int PH, int PW,
-                                                          const float* kxy, const int32_t* nk, int cap,
-                                                          float* sampled) {
-  const int i = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
-  if (i >= nk[b]) return;
+                                                          const float* kxy, const int32_t* koff, const int32_t* nk,
+                                                          int cap, float* sampled) {
+  const int b = blockIdx.y, c = threadIdx.x;
+  if ((int)blockIdx.x >= nk[b]) return;
+  const int i = koff[b] + blockIdx.x;
   const float kx = kxy[((size_t)b * cap + i) * 2], ky = kxy[((size_t)b * cap + i) * 2 + 1];
   const float gx = 2.0f * kx / (float)PW - 1.0f;
   const float gy = 2.0f * ky / (float)PH - 1.0f;
@@ -284,11 +297,11 @@ __global__ __launch_bounds__(256) void desc_sample_kernel(const float* desc_nhwc
 
 // one block per frame, thread = channel: sequential fma chain over the keypoints (canonical order).  The chain is
 // serial by definition, but its loads are not: 32 rows are fetched ahead of the 32 dependent fmas that consume them.
-__global__ __launch_bounds__(256) void desc_colnorm_kernel(const float* sampled, const int32_t* nk, int cap,
-                                                           float* dn) {
+__global__ __launch_bounds__(256) void desc_colnorm_kernel(const float* sampled, const int32_t* koff, const int32_t* nk,
+                                                           int cap, float* dn) {
   const int b = blockIdx.x, c = threadIdx.x;
   const int n = nk[b];
-  const float* s = sampled + (size_t)b * cap * 256 + c;
+  const float* s = sampled + ((size_t)b * cap + koff[b]) * 256 + c;
   float acc = 0.0f;
   int i = 0;
   for (; i + 32 <= n; i += 32) {
@@ -305,22 +318,59 @@ __global__ __launch_bounds__(256) void desc_colnorm_kernel(const float* sampled,
   dn[b * 256 + c] = sqrtf(acc);
 }
 
-__global__ __launch_bounds__(256) void desc_scale_kernel(const float* sampled, const float* dn, const int32_t* nk,
-                                                         int cap, float* out) {
-  const int i = blockIdx.x, b = blockIdx.y, c = threadIdx.x;
-  if (i >= nk[b]) return;
-  const size_t o = ((size_t)b * cap + i) * 256 + c;
+__global__ __launch_bounds__(256) void desc_scale_kernel(const float* sampled, const float* dn, const int32_t* koff,
+                                                         const int32_t* nk, int cap, float* out) {
+  const int b = blockIdx.y, c = threadIdx.x;
+  if ((int)blockIdx.x >= nk[b]) return;
+  const size_t o = ((size_t)b * cap + koff[b] + blockIdx.x) * 256 + c;
   out[o] = sampled[o] / dn[b * 256 + c];
 }
 
-void launch_descriptors(const float* desc_nhwc, int Hc, int Wc, int PH, int PW, const float* kxy, const int32_t* nk,
-                        int B, int cap, float* sampled, float* out, hipStream_t s) {
+void launch_descriptors(const float* desc_nhwc, int Hc, int Wc, int PH, int PW, const float* kxy, const int32_t* koff,
+                        const int32_t* nk, int B, int cap, int max_n, float* sampled, float* out, hipStream_t s) {
   // dn scratch lives at the tail of `sampled` (B*cap*256 floats followed by B*256)
   float* dn = sampled + (size_t)B * cap * 256;
-  hipLaunchKernelGGL(desc_sample_kernel, dim3(cap, B), dim3(256), 0, s, desc_nhwc, Hc, Wc, PH, PW, kxy, nk, cap,
+  hipLaunchKernelGGL(desc_sample_kernel, dim3(max_n, B), dim3(256), 0, s, desc_nhwc, Hc, Wc, PH, PW, kxy, koff, nk, cap,
                      sampled);
-  hipLaunchKernelGGL(desc_colnorm_kernel, dim3(B), dim3(256), 0, s, sampled, nk, cap, dn);
-  hipLaunchKernelGGL(desc_scale_kernel, dim3(cap, B), dim3(256), 0, s, sampled, dn, nk, cap, out);
+  hipLaunchKernelGGL(desc_colnorm_kernel, dim3(B), dim3(256), 0, s, sampled, koff, nk, cap, dn);
+  hipLaunchKernelGGL(desc_scale_kernel, dim3(max_n, B), dim3(256), 0, s, sampled, dn, koff, nk, cap, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::resize(8UC1 -> dw x dh, INTER_LINEAR): OpenCV's fixed-point path (coefficients x 2048, vertical pass
+// ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2), scale = 1 / ((double)dsize / ssize) as imgproc/resize.cpp.
+// Builds pyramid level k from level k-1 (SPextractor::ComputePyramid, src/SPextractor.cpp:631-656).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void resize_coef1(int d, double scale, int ssize, int& ofs, int& a0, int& a1) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f -= (float)s;
+  if (s < 0) { s = 0; f = 0.0f; }
+  if (s >= ssize - 1) { s = ssize - 1; f = 0.0f; }
+  ofs = s;
+  a0 = (int)(short)__float2int_rn((1.0f - f) * 2048.0f);
+  a1 = (int)(short)__float2int_rn(f * 2048.0f);
+}
+
+__global__ __launch_bounds__(256) void resize_u8c1_kernel(const uint8_t* src, int sw, int sh, int sstride, size_t sframe,
+                                                          uint8_t* dst, int dw, int dh) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+  if (x >= dw || y >= dh) return;
+  int xo, xa0, xa1, yo, yb0, yb1;
+  resize_coef1(x, 1.0 / ((double)dw / sw), sw, xo, xa0, xa1);
+  resize_coef1(y, 1.0 / ((double)dh / sh), sh, yo, yb0, yb1);
+  const int x1 = min(xo + 1, sw - 1), y1 = min(yo + 1, sh - 1);
+  const uint8_t* r0 = src + (size_t)b * sframe + (size_t)yo * sstride;
+  const uint8_t* r1 = src + (size_t)b * sframe + (size_t)y1 * sstride;
+  const int h0 = r0[xo] * xa0 + r0[x1] * xa1, h1 = r1[xo] * xa0 + r1[x1] * xa1;
+  int v = (((yb0 * (h0 >> 4)) >> 16) + ((yb1 * (h1 >> 4)) >> 16) + 2) >> 2;
+  dst[(size_t)b * dw * dh + (size_t)y * dw + x] = (uint8_t)min(max(v, 0), 255);
+}
+
+void launch_resize_u8c1(const uint8_t* src, int B, int sw, int sh, int sstride, size_t sframe, uint8_t* dst, int dw, int dh,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(resize_u8c1_kernel, dim3((dw + 63) / 64, (dh + 3) / 4, B), dim3(256), 0, s, src, sw, sh, sstride, sframe,
+                     dst, dw, dh);
 }
 
 // tests only: padded planar frame b -> dense [C][H][W]

@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256) void yolo_preproc_kernel(const uint8_t* bgr, i
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
   if (x >= dw || y >= dh) return;
   int xo, xa0, xa1, yo, yb0, yb1;
-  resize_coef(x, (double)sw / dw, sw, xo, xa0, xa1);
-  resize_coef(y, (double)sh / dh, sh, yo, yb0, yb1);
+  resize_coef(x, 1.0 / ((double)dw / sw), sw, xo, xa0, xa1);   // cv::resize: scale = 1 / ((double)dsize / ssize)
+  resize_coef(y, 1.0 / ((double)dh / sh), sh, yo, yb0, yb1);
   const int x1 = min(xo + 1, sw - 1), y1 = min(yo + 1, sh - 1);
   const uint8_t* r0 = bgr + (size_t)b * sframe + (size_t)yo * sstride;
   const uint8_t* r1 = bgr + (size_t)b * sframe + (size_t)y1 * sstride;

@@ -216,7 +216,7 @@ class Engine:
         else:
             B, H, W, stride = shape
             ptr, on_dev = C.c_void_p(device_ptr), 1
-        cap = cap or (nfeatures + 8)
+        cap = cap or (nfeatures + 8 + 4 * nlevels)
         p = _SpParams(nfeatures, scaleFactor, nlevels, iniTh, minTh)
         if boxes is None:
             boxes = [np.zeros((0, 4), np.int32)] * B

@@ -37,7 +37,7 @@ typedef enum dani_status {
   DANI_ERR_HIP = -3,         /* a HIP runtime call failed */
   DANI_ERR_WEIGHTS = -4,     /* missing / mis-shaped weight tensor (reference: std::exit, src/SPextractor.cpp:88-91) */
   DANI_ERR_CAPACITY = -5,    /* output buffer too small, *n_out holds the needed count */
-  DANI_ERR_UNSUPPORTED = -6, /* configuration not implemented (e.g. nlevels > 1) */
+  DANI_ERR_UNSUPPORTED = -6, /* configuration not implemented (e.g. a pyramid level smaller than 80x80) */
   DANI_ERR_EMPTY = -7        /* empty image (reference: operator() returns -1, src/SPextractor.cpp:135-136;
                                 Detect() returns false, src/YoloDetect.cpp:32-36) */
 } dani_status;

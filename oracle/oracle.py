@@ -221,6 +221,14 @@ def resize_bilinear_u8c3(img, dw, dh):
     return out
 
 
+def resize_bilinear_u8c1(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    sh, sw = img.shape
+    out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_bilinear_u8c1(img.ctypes.data_as(_u8), sw, sh, img.strides[0], out.ctypes.data_as(_u8), dw, dh)
+    return out
+
+
 def sigmoid(x):
     x = np.ascontiguousarray(x, np.float32)
     out = np.empty_like(x)

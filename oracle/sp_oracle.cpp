@@ -563,44 +563,67 @@ ORC_API int orc_features_per_level(int nfeatures, float scaleFactor, int nlevels
   return 0;
 }
 
-// Whole SPextractor::operator() for nlevels == 1 (the only setting the reference's tuned YAMLs
-// use, SURVEY.md section 5 Config row; pyramid levels > 0 need cv::resize, not restated yet).
-// Outputs: kpts n x (x, y), resp n, octave n, size n, desc n x 256; returns n (<= cap) or <0.
-// mono_index as returned by operator() (:164-216), incl. the "descriptors are not permuted" quirk.
+static void resize_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int cn, uint8_t* dst, int dw, int dh);
+
+// Whole SPextractor::operator() (src/SPextractor.cpp:130-217) incl. ComputePyramid (:631-656, level k =
+// cv::resize(level k-1, INTER_LINEAR) to cvRound(dim * invScale_k); the REFLECT_101 border only served ORB patches
+// and is never read by the SuperPoint path) and the per-level loop of ComputeKeyPointsOctTree (:219-386).
+// Outputs: kpts n x (x, y) in level-0 coordinates, resp n, octave n, size n, desc n x 256 (levels concatenated, each
+// level normalised over its own keypoints, Q7); returns n (<= cap) or <0.  mono_index as operator() returns it
+// (:164-216), incl. the "descriptors are not permuted" quirk.  prob_out / descmap_out: level 0 only.
 ORC_API int orc_sp_extract(const uint8_t* img, int W, int H, int stride, const float* const* weights, int nfeatures,
                            float scaleFactor, int nlevels, float iniTh, float minTh, const int32_t* boxes, int nboxes,
                            int lap0, int lap1, float* kpts_xy, float* resp, int32_t* octave, float* size,
                            float* desc, int cap, int* mono_index, float* prob_out, float* descmap_out) {
   if (!img || W <= 0 || H <= 0) return -1;  // operator() returns -1 on an empty image (:135-136)
-  if (nlevels != 1) return -2;
-  const int PH = (H / 8) * 8, PW = (W / 8) * 8, Hc = H / 8, Wc = W / 8;
-  std::vector<float> prob((size_t)PH * PW), dmap((size_t)256 * Hc * Wc);
-  if (orc_superpoint_forward(img, H, W, stride, weights, prob.data(), dmap.data(), nullptr)) return -3;
-  if (prob_out) memcpy(prob_out, prob.data(), prob.size() * sizeof(float));
-  if (descmap_out) memcpy(descmap_out, dmap.data(), dmap.size() * sizeof(float));
+  if (nlevels < 1) return -2;
   std::vector<int> fpl; std::vector<float> scales;
   features_per_level(nfeatures, scaleFactor, nlevels, fpl, scales);
-  std::vector<OKey> cand;
-  collect_candidates(prob.data(), PH, PW, W, H, iniTh, minTh, boxes, nboxes, scales[0], cand);
   const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
-  const int maxBorderX = W - EDGE_THRESHOLD + 3, maxBorderY = H - EDGE_THRESHOLD + 3;
-  std::vector<OKey> keys;
-  if (!cand.empty()) keys = distribute_octtree(cand, minBorderX, maxBorderX, minBorderY, maxBorderY, fpl[0]);
-  const int scaledPatchSize = (int)(PATCH_SIZE * scales[0]);
-  for (auto& k : keys) { k.x += minBorderX; k.y += minBorderY; k.octave = 0; k.size = (float)scaledPatchSize; }
-  const int n = (int)keys.size();
-  if (n > cap) return -4;
-  if (n > 0) {
-    std::vector<float> kxy((size_t)2 * n);
-    for (int i = 0; i < n; i++) { kxy[2 * i] = keys[i].x; kxy[2 * i + 1] = keys[i].y; }
-    orc_compute_descriptors(dmap.data(), 256, Hc, Wc, PH, PW, kxy.data(), n, desc);
+  std::vector<OKey> all;
+  std::vector<uint8_t> cur((size_t)W * H), nxt;
+  for (int y = 0; y < H; y++) memcpy(&cur[(size_t)y * W], img + (size_t)y * stride, W);
+  int cw = W, ch = H, n_total = 0;
+  for (int level = 0; level < nlevels; level++) {
+    if (level > 0) {
+      const float inv = 1.0f / scales[level];                       // mvInvScaleFactor[level]
+      const int nw = cv_round((float)W * inv), nh = cv_round((float)H * inv);
+      nxt.assign((size_t)nw * nh, 0);
+      resize_bilinear_u8(cur.data(), cw, ch, cw, 1, nxt.data(), nw, nh);
+      cur.swap(nxt); cw = nw; ch = nh;
+    }
+    if (cw < 8 || ch < 8) return -5;
+    const int PH = (ch / 8) * 8, PW = (cw / 8) * 8, Hc = ch / 8, Wc = cw / 8;
+    std::vector<float> prob((size_t)PH * PW), dmap((size_t)256 * Hc * Wc);
+    if (orc_superpoint_forward(cur.data(), ch, cw, cw, weights, prob.data(), dmap.data(), nullptr)) return -3;
+    if (level == 0 && prob_out) memcpy(prob_out, prob.data(), prob.size() * sizeof(float));
+    if (level == 0 && descmap_out) memcpy(descmap_out, dmap.data(), dmap.size() * sizeof(float));
+    std::vector<OKey> cand;
+    collect_candidates(prob.data(), PH, PW, cw, ch, iniTh, minTh, boxes, nboxes, scales[level], cand);
+    const int maxBorderX = cw - EDGE_THRESHOLD + 3, maxBorderY = ch - EDGE_THRESHOLD + 3;
+    std::vector<OKey> keys;
+    if (!cand.empty()) keys = distribute_octtree(cand, minBorderX, maxBorderX, minBorderY, maxBorderY, fpl[level]);
+    const int scaledPatchSize = (int)(PATCH_SIZE * scales[level]);
+    for (auto& k : keys) { k.x += minBorderX; k.y += minBorderY; k.octave = level; k.size = (float)scaledPatchSize; }
+    const int n = (int)keys.size();
+    if (n_total + n > cap) return -4;
+    if (n > 0) {
+      std::vector<float> kxy((size_t)2 * n);
+      for (int i = 0; i < n; i++) { kxy[2 * i] = keys[i].x; kxy[2 * i + 1] = keys[i].y; }
+      orc_compute_descriptors(dmap.data(), 256, Hc, Wc, PH, PW, kxy.data(), n, desc + (size_t)n_total * 256);
+    }
+    if (level != 0)
+      for (auto& k : keys) { k.x *= scales[level]; k.y *= scales[level]; }       // keypoint->pt *= scale (:190-192)
+    all.insert(all.end(), keys.begin(), keys.end());
+    n_total += n;
   }
   // mono / stereo-lapping partition of the KEYPOINTS only (:164-216)
+  const int n = n_total;
   int monoIndex = 0, stereoIndex = n - 1;
   std::vector<OKey> outk(n);
   for (int i = 0; i < n; i++) {
-    if (keys[i].x >= lap0 && keys[i].x <= lap1) outk[stereoIndex--] = keys[i];
-    else outk[monoIndex++] = keys[i];
+    if (all[i].x >= lap0 && all[i].x <= lap1) outk[stereoIndex--] = all[i];
+    else outk[monoIndex++] = all[i];
   }
   for (int i = 0; i < n; i++) {
     kpts_xy[2 * i] = outk[i].x; kpts_xy[2 * i + 1] = outk[i].y; resp[i] = outk[i].response;
@@ -675,39 +698,46 @@ ORC_API void orc_maxpool5(const float* in, int C, int H, int W, float* out) {
 // (INTER_RESIZE_COEF_BITS = 11: horizontal pass into int32 with coefficients scaled by 2048, vertical pass
 //  dst = ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  Used by YoloDetection::Detect,
 // /root/reference/src/YoloDetect.cpp:39.  (OpenCV itself is absent from this image; YOLO parity is box-level.)
-ORC_API void orc_resize_bilinear_u8c3(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh) {
-  const double sx = (double)sw / dw, sy = (double)sh / dh;
+static void resize_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int cn, uint8_t* dst, int dw, int dh) {
+  // cv::resize: inv_scale = (double)dsize / ssize; scale = 1. / inv_scale   (imgproc/resize.cpp)
+  const double sx = 1.0 / ((double)dw / sw), sy = 1.0 / ((double)dh / sh);
   std::vector<int> xofs(dw), yofs(dh);
   std::vector<short> xa(2 * dw), ya(2 * dh);
   auto coefs = [](int d, double scale, int ssize, int& ofs, short* ab) {
     float f = (float)((d + 0.5) * scale - 0.5);
     int s = (int)floorf(f);
     f -= s;
-    if (s < 0) { s = 0; f = 0; }
-    if (s >= ssize - 1) { s = ssize - 1; f = (s == ssize - 1 && ssize >= 1) ? 0.f : f; if (s > ssize - 1) s = ssize - 1; }
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= ssize - 1) { s = ssize - 1; f = 0.f; }
     ofs = s;
     ab[0] = (short)lrintf((1.f - f) * 2048.f);
     ab[1] = (short)lrintf(f * 2048.f);
   };
   for (int x = 0; x < dw; x++) coefs(x, sx, sw, xofs[x], &xa[2 * x]);
   for (int y = 0; y < dh; y++) coefs(y, sy, sh, yofs[y], &ya[2 * y]);
-  std::vector<int> r0((size_t)dw * 3), r1((size_t)dw * 3);
+  std::vector<int> r0((size_t)dw * cn), r1((size_t)dw * cn);
   auto hrow = [&](int srow, std::vector<int>& o) {
     srow = std::min(std::max(srow, 0), sh - 1);
     const uint8_t* S = src + (size_t)srow * sstride;
     for (int x = 0; x < dw; x++) {
       const int s0 = xofs[x], s1 = std::min(s0 + 1, sw - 1);
-      for (int c = 0; c < 3; c++) o[3 * x + c] = S[3 * s0 + c] * xa[2 * x] + S[3 * s1 + c] * xa[2 * x + 1];
+      for (int c = 0; c < cn; c++) o[cn * x + c] = S[cn * s0 + c] * xa[2 * x] + S[cn * s1 + c] * xa[2 * x + 1];
     }
   };
   for (int y = 0; y < dh; y++) {
     hrow(yofs[y], r0); hrow(yofs[y] + 1, r1);
     const int b0 = ya[2 * y], b1 = ya[2 * y + 1];
-    for (int i = 0; i < dw * 3; i++) {
+    for (int i = 0; i < dw * cn; i++) {
       const int v = (((b0 * (r0[i] >> 4)) >> 16) + ((b1 * (r1[i] >> 4)) >> 16) + 2) >> 2;
-      dst[(size_t)y * dw * 3 + i] = (uint8_t)std::min(std::max(v, 0), 255);
+      dst[(size_t)y * dw * cn + i] = (uint8_t)std::min(std::max(v, 0), 255);
     }
   }
+}
+ORC_API void orc_resize_bilinear_u8c3(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh) {
+  resize_bilinear_u8(src, sw, sh, sstride, 3, dst, dw, dh);
+}
+ORC_API void orc_resize_bilinear_u8c1(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh) {
+  resize_bilinear_u8(src, sw, sh, sstride, 1, dst, dw, dh);
 }
 
 // canonical sigmoid 1 / (1 + dani_expf(-x)) (Detect layer), elementwise

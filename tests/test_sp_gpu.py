@@ -121,7 +121,10 @@ def test_error_behaviour(engine, sp_weights):
     from dani_slam_amd import frontend
     img = synth.frame(0)
     with pytest.raises(frontend.DaniError) as ei:
-        engine.sp_extract_batch(img[None], nlevels=8)           # not implemented -> loud error, no fallback
+        engine.sp_extract_batch(img[None], nlevels=0)
+    assert ei.value.code == frontend.DANI_ERR_INVALID
+    with pytest.raises(frontend.DaniError) as ei:
+        engine.sp_extract_batch(img[None], nlevels=12)          # level 11 would be 86x64: loud error, no fallback
     assert ei.value.code == frontend.DANI_ERR_UNSUPPORTED
     with pytest.raises(frontend.DaniError) as ei:
         engine.sp_extract_batch(img[None], cap=10)
@@ -138,6 +141,24 @@ def test_error_behaviour(engine, sp_weights):
         e2.set_weights(bad)
     assert ei.value.code == frontend.DANI_ERR_WEIGHTS
     e2.close()
+
+
+@pytest.mark.parametrize("nlevels,nf,boxes,lap", [(4, 1000, [(200, 120, 160, 240)], (0, 300)), (8, 1000, [], (0, 0)),
+                                                    (2, 1250, [(10, 10, 300, 200), (400, 300, 100, 100)], (0, 1000))])
+def test_pyramid_levels_match_oracle(engine, sp_weights, oracle_frames, nlevels, nf, boxes, lap):
+    """nLevels > 1: ComputePyramid (fixed-point cv::resize chain), per-level network / cells / quadtree / descriptors,
+    the scaled dynamic-box cull with its f32 drift (Q6), octave / size fields and the cross-level mono/stereo partition."""
+    img = oracle_frames[1][0]
+    ref = oracle.sp_extract(img, sp_weights, nfeatures=nf, nlevels=nlevels, boxes=boxes, lapping=lap)
+    r = engine.sp_extract_batch(img[None], nfeatures=nf, nlevels=nlevels, boxes=[np.array(boxes, np.int32).reshape(-1, 4)],
+                                lapping=lap)[0]
+    assert len(r["kpts"]) == len(ref["kpts"]) and len(ref["kpts"]) > nf // 2
+    assert np.array_equal(r["octave"], ref["octave"]) and len(np.unique(ref["octave"])) == nlevels
+    assert np.array_equal(r["size"], ref["size"])
+    assert np.array_equal(r["kpts"], ref["kpts"])
+    assert np.array_equal(r["resp"], ref["resp"])
+    assert r["mono_index"] == ref["mono_index"]
+    assert np.array_equal(r["desc"], ref["desc"])
 
 
 def test_reference_style_wrapper(engine, oracle_frames):
