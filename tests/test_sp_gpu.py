@@ -177,3 +177,43 @@ def test_flat_image_no_crash(engine, sp_weights):
     ref = oracle.sp_extract(img, sp_weights)
     r = engine.sp_extract_batch(img[None])[0]
     assert np.array_equal(r["kpts"], ref["kpts"])
+
+
+def test_two_threads_like_the_stereo_frame_constructor(sp_weights, oracle_frames):
+    """Frame::Frame(imL, imR) runs two extractors concurrently from two std::threads (src/Frame.cc:124-127): the ABI is
+    re-entrant per engine (private stream + workspace per call)."""
+    import threading
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=1, n_contexts=2, weights=sp_weights)
+    left = frontend.SPextractor(1024, 1.2, 1, 0.015, 0.007, engine=e)
+    right = frontend.SPextractor(1024, 1.2, 1, 0.015, 0.007, engine=e)
+    out = {}
+
+    def run(name, ex, img):
+        for _ in range(3):
+            out[name] = ex(img, None, (0, 0))
+    ts = [threading.Thread(target=run, args=("L", left, oracle_frames[0][0])),
+          threading.Thread(target=run, args=("R", right, oracle_frames[1][0]))]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for name, i in (("L", 0), ("R", 1)):
+        mono, kps, desc = out[name]
+        ref = oracle_frames[i][1]
+        assert np.array_equal(np.array([[k.x, k.y] for k in kps], np.float32), ref["kpts"])
+        assert np.array_equal(desc, ref["desc"])
+    e.close()
+
+
+@pytest.mark.parametrize("w,h", [(752, 480), (1280, 720), (328, 248)])
+def test_other_image_sizes(sp_weights, w, h):
+    """EuRoC (752x480), 720p and a small non-multiple-of-32 size."""
+    from dani_slam_amd import frontend
+    rng = np.random.RandomState(w)
+    base = synth.frame(5)
+    img = np.ascontiguousarray(np.tile(base, (2, 2))[:h, :w])
+    img = (img.astype(np.int32) + rng.randint(-3, 4, img.shape)).clip(0, 255).astype(np.uint8)
+    e = frontend.Engine(device=0, max_batch=1, max_width=w, max_height=h, weights=sp_weights)
+    ref = oracle.sp_extract(img, sp_weights, nfeatures=1500)
+    r = e.sp_extract_batch(img[None], nfeatures=1500)[0]
+    assert np.array_equal(r["kpts"], ref["kpts"]) and np.array_equal(r["desc"], ref["desc"])
+    e.close()
