@@ -384,3 +384,58 @@ void launch_copy_layer_dense(const ActDesc& a, int b, float* out_dense, hipStrea
 }
 
 }  // namespace dani
+
+// =================================================================================================
+// the descriptor-distance scans of the projection searches.
+// LGmatcher::DescriptorDistance = (float) cv::norm(a, b, NORM_L2) over 256 floats (src/LGmatcher.cpp:2009-2013;
+// OpenCV: float difference, squared and accumulated in double, sqrt) and the best / second-best bookkeeping of
+// LGmatcher::SearchByProjection (src/LGmatcher.cpp:84-120): candidates are visited in list order, strict `<`.
+// One wavefront per query (map-point descriptor), 4 dimensions per lane; bound: HBM (1 KiB per candidate row).
+// =================================================================================================
+namespace dani {
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, off); hi = __shfl_xor(hi, off);
+    v += __hiloint2double(hi, lo);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void desc_best2_kernel(const float* q, const float* t, const int32_t* t_level,
+                                                        const int32_t* cand_off, const int32_t* cand_idx, int nq,
+                                                        float* best_dist, float* best_dist2, int32_t* best_idx,
+                                                        int32_t* best_level, int32_t* best_level2) {
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  if (qi >= nq) return;
+  const float4 a = reinterpret_cast<const float4*>(q + (size_t)qi * 256)[lane];
+  float bd = 256.0f, bd2 = 256.0f;
+  int bl = -1, bl2 = -1, bi = -1;
+  const int c0 = cand_off[qi], c1 = cand_off[qi + 1];
+  for (int c = c0; c < c1; c++) {
+    const int idx = cand_idx[c];
+    const float4 b = reinterpret_cast<const float4*>(t + (size_t)idx * 256)[lane];
+    const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+    double s = (double)d0 * (double)d0 + (double)d1 * (double)d1 + (double)d2 * (double)d2 + (double)d3 * (double)d3;
+    s = wave_sum_f64(s);
+    const float dist = (float)sqrt(s);
+    const int lvl = t_level ? t_level[idx] : 0;
+    if (dist < bd) { bd2 = bd; bd = dist; bl2 = bl; bl = lvl; bi = idx; }
+    else if (dist < bd2) { bl2 = lvl; bd2 = dist; }
+  }
+  if (lane == 0) {
+    best_dist[qi] = bd; best_dist2[qi] = bd2; best_idx[qi] = bi; best_level[qi] = bl; best_level2[qi] = bl2;
+  }
+}
+
+void launch_desc_best2(const float* q, const float* t, const int32_t* t_level, const int32_t* cand_off,
+                       const int32_t* cand_idx, int nq, float* best_dist, float* best_dist2, int32_t* best_idx,
+                       int32_t* best_level, int32_t* best_level2, hipStream_t s) {
+  if (nq > 0)
+    hipLaunchKernelGGL(desc_best2_kernel, dim3(nq), dim3(64), 0, s, q, t, t_level, cand_off, cand_idx, nq, best_dist, best_dist2,
+                       best_idx, best_level, best_level2);
+}
+
+}  // namespace dani

@@ -97,6 +97,7 @@ def load_library():
                                         _i32, C.c_int32, _i32, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_reset.argtypes = [C.c_void_p, C.c_int32]
     lib.dani_frontend_timings.argtypes = [C.c_void_p, _f]
+    lib.dani_desc_best2.argtypes = [C.c_void_p, _f, C.c_int32, _f, C.c_int32, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32]
     lib.dani_host_distribute_octtree.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.c_int32, _i32, C.c_int32]
     lib.dani_host_cell_grid.argtypes = [C.c_int32, C.c_int32, _i32, C.c_int32]
@@ -389,6 +390,23 @@ class Engine:
         ms = np.zeros(4, np.float32)
         self._check(self.lib.dani_frontend_timings(self.h, _fp(ms)))
         return ms
+
+    # -- projection-search descriptor scans -----------------------------------------
+    def desc_best2(self, q_desc, t_desc, t_level, cand_lists):
+        """LGmatcher::DescriptorDistance + best/second-best scan (src/LGmatcher.cpp:84-120, 2009-2013).
+        cand_lists: list (len nq) of index lists into t_desc.  Returns arrays (bestDist, bestDist2, bestIdx, bestLevel, bestLevel2)."""
+        q = np.ascontiguousarray(q_desc, np.float32).reshape(-1, 256); t = np.ascontiguousarray(t_desc, np.float32).reshape(-1, 256)
+        nq, nt = len(q), len(t)
+        offs = np.zeros(nq + 1, np.int32)
+        for i, cl in enumerate(cand_lists):
+            offs[i + 1] = offs[i] + len(cl)
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(cl, np.int32) for cl in cand_lists]) if offs[nq] else np.zeros(1, np.int32), np.int32)
+        lvl = np.ascontiguousarray(t_level, np.int32) if t_level is not None else None
+        bd = np.empty(nq, np.float32); bd2 = np.empty(nq, np.float32)
+        bi = np.empty(nq, np.int32); bl = np.empty(nq, np.int32); bl2 = np.empty(nq, np.int32)
+        self._check(self.lib.dani_desc_best2(self.h, _fp(q), nq, _fp(t), nt, _ip(lvl) if lvl is not None else None, _ip(offs), _ip(idx),
+                                             _fp(bd), _fp(bd2), _ip(bi), _ip(bl), _ip(bl2)))
+        return bd, bd2, bi, bl, bl2
 
     def set_profiling(self, on=True):
         self._check(self.lib.dani_set_profiling(self.h, int(on)))

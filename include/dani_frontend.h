@@ -232,6 +232,21 @@ DANI_API int dani_frontend_reset(dani_engine* e, int32_t sequence);
 /* Stage wall times (ms) of the last dani_frontend_batch on this thread: [0] yolo, [1] superpoint, [2] lightglue, [3] total. */
 DANI_API int dani_frontend_timings(dani_engine* e, float* ms4);
 
+/* ---- projection-search descriptor scans -------------------------- */
+
+/* Replaces LGmatcher::DescriptorDistance (src/LGmatcher.cpp:2009-2013: (float) cv::norm(a, b, NORM_L2) over 256
+ * floats) and the best / second-best bookkeeping inside LGmatcher::SearchByProjection (src/LGmatcher.cpp:84-120; the
+ * same scan appears at :444-464, :1694-1719, :1901-1916).  The caller (host, unchanged geometry code) builds, for each
+ * of the nq query descriptors (map points), the candidate list Frame::GetFeaturesInArea returned minus the entries its
+ * own checks reject, as CSR (cand_offsets [nq+1], cand_idx); the engine visits each list in order with strict `<`:
+ *   bestDist = bestDist2 = 256, levels = -1, bestIdx = -1;  dist < bestDist -> shift best to second; else
+ *   dist < bestDist2 -> update second.  t_level = octave of every train keypoint (may be NULL -> 0).
+ * All pointers are HOST pointers (descriptors are uploaded once per call); outputs have nq entries. */
+DANI_API int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt,
+                             const int32_t* t_level, const int32_t* cand_offsets, const int32_t* cand_idx,
+                             float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
+                             int32_t* best_level2);
+
 /* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
 
 /* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.
