@@ -39,6 +39,7 @@ const ConvVariant kSpVariant[12] = {
     CONV3_BLK16_RELU, CONV1_BLK16_LINEAR, CONV3_BLK16_RELU, CONV1_BLK16_LINEAR};
 
 constexpr int CAND_CAP = 32768;  // candidates per frame kept on the device (reference reserves 10*nfeatures)
+constexpr int CAND_FAST = 4096;  // candidates per frame read back together with the counts (typical frames: 3-4 k)
 
 struct Context {
   hipStream_t stream = nullptr;
@@ -565,21 +566,28 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
                       19 - 3, scales[l], L.slot_xyr, L.slot_count, L.slot_stride, s);
       launch_cell_compact(L.slot_xyr, L.slot_count, ncells, L.slot_stride, B, L.cand, L.cand_count, CAND_CAP, s);
       HIP_TRY(e, hipMemcpyAsync(L.h_cand_count, L.cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+      // optimistic read-back of the first CAND_FAST candidates of every frame in the same stream pass (one sync
+      // instead of two); frames with more candidates get a second copy below
+      HIP_TRY(e, hipMemcpy2DAsync(L.h_cand, (size_t)CAND_CAP * 12, L.cand, (size_t)CAND_CAP * 12, (size_t)CAND_FAST * 12, B, hipMemcpyDeviceToHost, s));
     }
   }
   HIP_TRY(e, hipEventRecord(c->ev[2], s));
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipStreamSynchronize(s));
+  bool more = false;
   for (int l = 0; l < NL; l++) {
     Context::Level& L = c->lv[l];
     for (int b = 0; b < B; b++) {
       int nc = L.cells.empty() ? 0 : L.h_cand_count[b];
       if (nc > CAND_CAP) return fail(e, DANI_ERR_CAPACITY, "frame %d level %d has %d candidates (> %d)", b, l, nc, CAND_CAP);
       L.h_cand_count[b] = nc;
-      if (nc) HIP_TRY(e, hipMemcpyAsync(L.h_cand + (size_t)b * CAND_CAP * 3, L.cand + (size_t)b * CAND_CAP * 3, (size_t)nc * 12, hipMemcpyDeviceToHost, s));
+      if (nc > CAND_FAST) {
+        more = true;
+        HIP_TRY(e, hipMemcpyAsync(L.h_cand + ((size_t)b * CAND_CAP + CAND_FAST) * 3, L.cand + ((size_t)b * CAND_CAP + CAND_FAST) * 3, (size_t)(nc - CAND_FAST) * 12, hipMemcpyDeviceToHost, s));
+      }
     }
   }
-  HIP_TRY(e, hipStreamSynchronize(s));
+  if (more) HIP_TRY(e, hipStreamSynchronize(s));
 
   // ---- host: quadtree per (frame, level), keypoint assembly (SPextractor.cpp:359-376, :164-216)
   const auto t0 = std::chrono::steady_clock::now();
