@@ -18,7 +18,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdani_frontend.so")
+LIB_PATH = os.environ.get("DANI_FRONTEND_LIB", os.path.join(_HERE, "lib", "libdani_frontend.so"))   # override: kernel A/B experiments
 
 _f = C.POINTER(C.c_float)
 _i32 = C.POINTER(C.c_int32)
