@@ -435,7 +435,6 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
   }
   ATK_PREFETCH(0);
   for (int it = 0; it < half; it++) {
-#ifndef DANI_EXP_D
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -444,7 +443,6 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
     }
     __syncthreads();
     if (it + 1 < half) ATK_PREFETCH(it + 1);
-#endif
     const int kt = kh * half + it;                        // this wave's key tile
     if (wave_active && kt < ntiles) {
       f32x16 s;
