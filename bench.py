@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
+                    help="frames per GPU per step (default 8 = BASELINE config #4's 64 frames / 8 GPUs)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand the frames over as HOST buffers (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--sequences", type=int, default=1,
@@ -105,7 +107,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from dani_slam_amd import sharding
-    B = FRAMES_PER_GPU
+    B = args.frames_per_gpu
     shard = sharding.shard_frames(B * world, rank, world)   # this rank's block of the synthetic frames
     frames = np.stack([synth.frame(i) for i in shard])
     frames_bgr = np.stack([synth.frame_bgr(i) for i in shard])
