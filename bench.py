@@ -99,12 +99,18 @@ def main():
     import torch.distributed as dist
     from dani_slam_amd import frontend, synth
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # rehearsal knobs (1-GPU box): DANI_BENCH_BACKEND=gloo DANI_BENCH_ONE_DEVICE=1 runs all ranks on GPU 0 over gloo
+    backend = os.environ.get("DANI_BENCH_BACKEND", "nccl")
+    if os.environ.get("DANI_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm (xGMI on the MI355X node)
+        else:
+            dist.init_process_group(backend)
 
     from dani_slam_amd import sharding
     B = args.frames_per_gpu
@@ -153,6 +159,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    reduce_dev = dev if backend == "nccl" else None
 
     run_steps(max(args.warmup, NSEQ), False)
     eng.set_profiling(True)
@@ -164,7 +171,7 @@ def main():
     eng.set_profiling(False)
     out = next(o for o in outs if o is not None)
 
-    dt_max = sharding.reduce_max_seconds(dt, dev)
+    dt_max = sharding.reduce_max_seconds(dt, reduce_dev)
     nk = [len(o["kpts"]) for o in out]
 
     if rank == 0:
