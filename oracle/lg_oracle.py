@@ -17,6 +17,9 @@ final_proj / matchability, sigmoid-log-double-softmax, mutual-nearest-neighbour 
 point pruning -- the exported "end-to-end" forward(kpts0, kpts1, desc0, desc1) -> (matches[K,2], scores[K])
 convention the reference's call site uses).  Weight names follow the public checkpoint
 (posenc.Wr.weight, transformers.{i}.self_attn.Wqkv.weight, ..., log_assignment.{i}.final_proj.weight).
+What IS pinned is the arithmetic of this restatement: tests/golden/make_golden_nets.py writes the same architecture a
+second time with ATen operators (scaled_dot_product_attention, layer_norm, gelu, log_softmax, logsigmoid) and
+tests/test_oracle_golden_nets.py holds this module to the committed vectors (tests/golden/lg_g7.npz).
 """
 from __future__ import annotations
 

@@ -17,6 +17,9 @@ model.24.m.0.weight).  Everything AFTER the network (score filter, xywh->xyxy, c
 rescale with the reference's 640/384 constants (quirk Q10), int truncation, placeholder box, static-box
 subtraction) is a literal restatement of the cited lines.  The convolutions use the repo's canonical f32 chain
 (oracle/sp_oracle.cpp: orc_conv2d_ex), SiLU = x / (1 + dani_expf(-x)).
+What IS pinned is the arithmetic of the network restatement: tests/golden/make_golden_nets.py writes the same
+architecture with ATen operators (conv2d, silu, max_pool2d, interpolate) and tests/test_oracle_golden_nets.py holds
+the three raw head tensors to the committed vectors (tests/golden/yolo_g8.npz).
 """
 from __future__ import annotations
 
