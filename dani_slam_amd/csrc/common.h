@@ -123,14 +123,15 @@ void launch_desc_best2(const float* q, const float* t, const int32_t* t_level, c
                        int32_t* best_level, int32_t* best_level2, hipStream_t s);
 
 // ---- LightGlue kernels (lg_kernels.hip) ------------------------------------------------------------
-struct LgSet { int tok_off, n, partner_off, partner_n; float size_w, size_h; };
+// one keypoint set of a LightGlue batch; kp / desc point at the set's own token-major inputs ([n][2], [n][256]) so
+// that device-resident SuperPoint outputs are read in place (no gather copies)
+struct LgSet { int tok_off, n, partner_off, partner_n; float size_w, size_h; const float* kp; const float* desc; };
 void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s);
 void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s);
-void launch_posenc(const float* kpts, const LgSet* sets, int nsets, int max_np, const float* wr, float* cosb,
-                   float* sinb, int ld, hipStream_t s);
-void launch_desc_to_fm(const float* desc_tm, const LgSet* sets, int nsets, int max_np, float* x, int ld, hipStream_t s);
+void launch_posenc(const LgSet* sets, int nsets, int max_np, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s);
+void launch_desc_to_fm(const LgSet* sets, int nsets, int max_np, float* x, int ld, hipStream_t s);
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_n, int cross, float scale, hipStream_t s);
 void launch_matchability(const float* x, const float* w, float b, float* logsig, int T, int ld, hipStream_t s);

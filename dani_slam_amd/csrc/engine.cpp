@@ -44,7 +44,7 @@ constexpr int CAND_FAST = 4096;  // candidates per frame read back together with
 struct Context {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // YOLO (concurrent with the SuperPoint conv stack) and overlapped D2H copies
-  hipEvent_t ev_desc = nullptr, ev_y0 = nullptr, ev_y1 = nullptr;
+  hipEvent_t ev_desc = nullptr, ev_y0 = nullptr, ev_y1 = nullptr, ev_lg0 = nullptr, ev_lg1 = nullptr;
   int W = 0, H = 0, B = 0;  // shapes the buffers are built for
   int nlevels = 0;
   float scale_factor = 0.0f;
@@ -81,6 +81,7 @@ struct Context {
   int kcap = 0;
   // pinned host staging
   float* h_kxy = nullptr;  // [B][kcap][2] followed by per-level (offset, count) ints [nlevels][2][B]
+  float* h_desc = nullptr; // [B][kcap][256]: descriptor read-back of the fused call (copied out under LightGlue)
   int32_t* h_boxes = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t lev[13] = {};
@@ -196,6 +197,14 @@ HostPool& host_pool() {
 }
 
 thread_local Context* t_last_ctx = nullptr;
+// the debug / timing entry points read "the last context of this thread": only if it still belongs to engine e
+Context* last_ctx(dani_engine* e) {
+  Context* c = t_last_ctx;
+  if (!e || !c) return nullptr;
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (Context* x : e->ctxs) if (x == c) return c;
+  return nullptr;
+}
 thread_local Context* t_borrowed = nullptr;     // set by dani_frontend_batch: nested ABI calls reuse its context
 thread_local bool t_keep_desc_on_device = false;
 thread_local int t_sp_phase = 0;          // 0: whole extractor; 1: enqueue the network only; 2: everything after it
@@ -321,6 +330,7 @@ int ensure_shapes(dani_engine* e, Context* c, int W, int H, int B, int kcap, int
   c->prev_n = 0;
   if ((rc = host_alloc(e, c, (void**)&c->h_kxy, ((size_t)B * kcap * 2 + nints) * 4))) return rc;
   if ((rc = host_alloc(e, c, (void**)&c->h_boxes, (size_t)(c->box_cap * 4 + B + 1) * 4))) return rc;
+  if ((rc = host_alloc(e, c, (void**)&c->h_desc, (size_t)B * kcap * 256 * 4))) return rc;
   HIP_TRY(e, hipStreamSynchronize(c->stream));
   c->W = W; c->H = H; c->B = B; c->nlevels = nlevels; c->scale_factor = scaleFactor;
   return 0;
@@ -336,6 +346,15 @@ int check_params(dani_engine* e, int W, int H, const dani_sp_params* p) {
     return fail(e, DANI_ERR_INVALID, "image %dx%d exceeds the engine's configured maximum %dx%d", W, H, e->cfg.max_width, e->cfg.max_height);
   if (p->nfeatures <= 0 || !(p->ini_th >= 0.0f) || !(p->min_th >= 0.0f)) return fail(e, DANI_ERR_INVALID, "bad extractor params");
   return 0;
+}
+
+void sp_read_timers(Context* c, bool prof) {
+  (void)hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[2]);
+  (void)hipEventElapsedTime(&c->ms[3], c->ev[3], c->ev[4]);
+  (void)hipEventElapsedTime(&c->ms[4], c->ev[0], c->ev[4]);
+  if (prof)
+    for (int i = 0; i < 12; i++) (void)hipEventElapsedTime(&c->layer_ms[i], c->lev[i], c->lev[i + 1]);
 }
 
 }  // namespace
@@ -371,6 +390,7 @@ int dani_engine_create(const dani_config* cfg, dani_engine** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         create_priority_stream(&c->stream2) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
     (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
+    (void)hipEventCreate(&c->ev_lg0); (void)hipEventCreate(&c->ev_lg1);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     for (auto& ev : c->lev) (void)hipEventCreate(&ev);
     e->ctxs.push_back(c);
@@ -379,14 +399,25 @@ int dani_engine_create(const dani_config* cfg, dani_engine** out) {
   return DANI_OK;
 }
 
+namespace {
+int lg_finalize(dani_engine* e); int yolo_finalize(dani_engine* e);
+// the LightGlue / YOLO / sequence side tables are keyed by engine and context addresses: they must die with them
+void lg_release(dani_engine* e); void yolo_release(dani_engine* e); void seq_release(dani_engine* e);
+}
+
 void dani_engine_destroy(dani_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   for (Context* c : e->ctxs) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  }
+  lg_release(e); yolo_release(e); seq_release(e);
+  for (Context* c : e->ctxs) {
     free_buffers(c);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->lev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {c->ev_desc, c->ev_y0, c->ev_y1, c->ev_lg0, c->ev_lg1}) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -428,7 +459,7 @@ int dani_load_weights_file(dani_engine* e, const char* path) {
 }
 
 }  // extern "C"
-namespace { int lg_finalize(dani_engine* e); int yolo_finalize(dani_engine* e); }
+
 extern "C" {
 
 int dani_finalize_weights(dani_engine* e) {
@@ -654,19 +685,18 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   if (desc) {   // descriptor read-back on the second stream so that it can run under the next stage's kernels
     HIP_TRY(e, hipEventRecord(c->ev_desc, s));
     HIP_TRY(e, hipStreamWaitEvent(c->stream2, c->ev_desc, 0));
+    // fused call: into pinned staging (a copy into pageable memory would block this thread until it is done); the
+    // caller moves it to `desc` while LightGlue runs
     for (int b = 0; b < B; b++)
       if (n_out[b])
-        HIP_TRY(e, hipMemcpyAsync(desc + (size_t)b * cap * 256, c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, c->stream2));
+        HIP_TRY(e, hipMemcpyAsync(t_defer_desc_sync ? c->h_desc + (size_t)b * c->kcap * 256 : desc + (size_t)b * cap * 256,
+                                  c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, c->stream2));
     if (!t_defer_desc_sync) HIP_TRY(e, hipStreamSynchronize(c->stream2));
   }
-  HIP_TRY(e, hipStreamSynchronize(s));
   HIP_TRY(e, hipGetLastError());
-  (void)hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]);
-  (void)hipEventElapsedTime(&c->ms[1], c->ev[1], c->ev[2]);
-  (void)hipEventElapsedTime(&c->ms[3], c->ev[3], c->ev[4]);
-  (void)hipEventElapsedTime(&c->ms[4], c->ev[0], c->ev[4]);
-  if (prof)
-    for (int i = 0; i < 12; i++) (void)hipEventElapsedTime(&c->layer_ms[i], c->lev[i], c->lev[i + 1]);
+  if (t_defer_desc_sync) return DANI_OK;   // the fused call synchronises (and reads the timers) after LightGlue
+  HIP_TRY(e, hipStreamSynchronize(s));
+  sp_read_timers(c, prof);
   return DANI_OK;
 }
 
@@ -680,7 +710,7 @@ int dani_sp_extract(dani_engine* e, const uint8_t* img, int32_t W, int32_t H, in
 
 int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* desc_map, float* cand_xyr, int32_t cand_cap,
                         int32_t* n_cand) {
-  Context* c = t_last_ctx;
+  Context* c = last_ctx(e);
   if (!e || !c || b < 0 || b >= c->B) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
   HIP_TRY(e, hipSetDevice(e->device));
   if (c->lv.empty()) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
@@ -699,7 +729,7 @@ int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* desc_map,
 }
 
 int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, int64_t count) {
-  Context* c = t_last_ctx;
+  Context* c = last_ctx(e);
   if (!e || !c || b < 0 || b >= c->B || layer < 0 || layer >= 12 || !out) return fail(e, DANI_ERR_INVALID, "bad argument");
   if (c->lv.empty()) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
   const ActDesc& a = c->lv[0].act[layer];
@@ -717,14 +747,14 @@ int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, in
 }
 
 int dani_last_timings(dani_engine* e, float* ms, int32_t n) {
-  Context* c = t_last_ctx;
+  Context* c = last_ctx(e);
   if (!e || !c || !ms) return DANI_ERR_INVALID;
   for (int i = 0; i < n && i < 5; i++) ms[i] = c->ms[i];
   return DANI_OK;
 }
 
 int dani_layer_timings(dani_engine* e, float* ms12) {
-  Context* c = t_last_ctx;
+  Context* c = last_ctx(e);
   if (!e || !c || !ms12) return DANI_ERR_INVALID;
   for (int i = 0; i < 12; i++) ms12[i] = c->layer_ms[i];
   return DANI_OK;
@@ -809,6 +839,22 @@ LgWeights* lg_weights(dani_engine* e) {
   LgWeights* w = new LgWeights();
   g_lg_w[e] = w;
   return w;
+}
+
+void lg_release(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (Context* c : e->ctxs) {
+    auto it = g_lg_ctx.find(c);
+    if (it == g_lg_ctx.end()) continue;
+    LgContext* L = it->second;
+    for (void* p : L->dev_allocs) (void)hipFree(p);
+    for (void* p : L->host_allocs) (void)hipHostFree(p);
+    if (L->aev_ready) for (auto& ev : L->aev) (void)hipEventDestroy(ev);
+    delete L;
+    g_lg_ctx.erase(it);
+  }
+  auto w = g_lg_w.find(e);
+  if (w != g_lg_w.end()) { delete w->second; g_lg_w.erase(w); }   // device weights are in e->weight_allocs
 }
 
 int lg_upload(dani_engine* e, const std::vector<float>& v, float** out) {
@@ -962,22 +1008,22 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
   int rc;
 #define LGA(ptr, rows) if ((rc = lg_dev(e, L, (void**)&(ptr), (size_t)(rows) * ld * 4))) return rc;
   LGA(L->x, 256) LGA(L->qkv, 768) LGA(L->ctx, 256) LGA(L->msg, 256) LGA(L->hbuf, 512) LGA(L->qk, 256) LGA(L->v, 256)
-  LGA(L->cosb, 32) LGA(L->sinb, 32) LGA(L->md, 256) LGA(L->logsig, 1) LGA(L->lse_row, 1) LGA(L->lse_col, 1) LGA(L->max0, 1)
-  LGA(L->m0, 1) LGA(L->m1, 1) LGA(L->kpts, 2) LGA(L->desc_tm, 256)
+  LGA(L->cosb, 32) LGA(L->sinb, 32) LGA(L->md, 256) LGA(L->logsig, 1) LGA(L->lse_row, 1) LGA(L->lse_col, 1)
+  LGA(L->m0, 3) LGA(L->kpts, 2) LGA(L->desc_tm, 256)   // m0 | m1 | max0 are rows of one block: one read-back
+  L->m1 = L->m0 + ld; L->max0 = reinterpret_cast<float*>(L->m0 + 2 * (size_t)ld);
 #undef LGA
   L->sim_ld = round_up(np + 128, 64);
   if ((rc = lg_dev(e, L, (void**)&L->sim, (size_t)pairs * (np + 64) * L->sim_ld * 4))) return rc;
   if ((rc = lg_dev(e, L, (void**)&L->d_sets, sizeof(LgSet) * 2 * pairs))) return rc;
   if ((rc = lg_host(e, L, (void**)&L->h_sets, sizeof(LgSet) * 2 * pairs))) return rc;
   if ((rc = lg_host(e, L, (void**)&L->h_stage, (size_t)ld * 258 * 4))) return rc;
-  if ((rc = lg_host(e, L, (void**)&L->h_m0, (size_t)ld * 4))) return rc;
-  if ((rc = lg_host(e, L, (void**)&L->h_m1, (size_t)ld * 4))) return rc;
-  if ((rc = lg_host(e, L, (void**)&L->h_max0, (size_t)ld * 4))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_m0, (size_t)ld * 12))) return rc;
+  L->h_m1 = L->h_m0 + ld; L->h_max0 = reinterpret_cast<float*>(L->h_m0 + 2 * (size_t)ld);
   L->pairs = pairs; L->kmax = kmax; L->ld = ld;
   return 0;
 }
 
-// the 9-layer forward + assignment statistics on stream s; inputs already in L->kpts / L->desc_tm / L->d_sets
+// the 9-layer forward + assignment statistics on stream s; the sets in L->d_sets point at their token-major inputs
 void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, hipStream_t s, bool prof) {
   const int ld = L->ld, max_np = round_up(max_n, 32);
   if (prof && !L->aev_ready) { for (auto& ev : L->aev) (void)hipEventCreate(&ev); L->aev_ready = true; }
@@ -987,8 +1033,8 @@ void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, h
     launch_attention(Q, K, V, L->ctx, ld, L->d_sets, nsets, max_n, cross, scale, s);
     if (prof) (void)hipEventRecord(L->aev[ai++], s);
   };
-  launch_desc_to_fm(L->desc_tm, L->d_sets, nsets, max_np, L->x, ld, s);
-  launch_posenc(L->kpts, L->d_sets, nsets, max_np, W->wr, L->cosb, L->sinb, ld, s);
+  launch_desc_to_fm(L->d_sets, nsets, max_np, L->x, ld, s);
+  launch_posenc(L->d_sets, nsets, max_np, W->wr, L->cosb, L->sinb, ld, s);
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
     launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
   };
@@ -1016,6 +1062,13 @@ void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, h
 }
 
 thread_local LgContext* t_last_lg = nullptr;
+LgContext* last_lg(dani_engine* e) {
+  if (!e || !t_last_lg) return nullptr;
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (Context* c : e->ctxs) { auto it = g_lg_ctx.find(c); if (it != g_lg_ctx.end() && it->second == t_last_lg) return t_last_lg; }
+  return nullptr;
+}
+thread_local std::function<void()>* t_overlap_fn = nullptr;   // set by the fused front-end around its LightGlue call
 
 }  // namespace
 
@@ -1075,28 +1128,32 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
         st.size_w = st.n ? 1.0f + (mxx - mnx) : 1.0f; st.size_h = st.n ? 1.0f + (mxy - mny) : 1.0f;
       }
     }
-  memcpy(L->h_sets, L->last_sets.data(), sizeof(LgSet) * 2 * P);
-  HIP_TRY(e, hipMemcpyAsync(L->d_sets, L->h_sets, sizeof(LgSet) * 2 * P, hipMemcpyHostToDevice, s));
+  // inputs: device-resident sets are read in place; host sets go through ONE pinned staging block and two copies
   for (int p = 0; p < P; p++)
     for (int side = 0; side < 2; side++) {
-      const LgSet& st = L->last_sets[2 * p + side];
-      if (!st.n) continue;
+      LgSet& st = L->last_sets[2 * p + side];
       const float* k = (side ? kpts1 : kpts0) + (size_t)p * in_cap * 2;
       const float* d = (side ? desc1 : desc0) + (size_t)p * in_cap * 256;
-      const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-      HIP_TRY(e, hipMemcpyAsync(L->kpts + (size_t)st.tok_off * 2, k, (size_t)st.n * 8, kind, s));
-      HIP_TRY(e, hipMemcpyAsync(L->desc_tm + (size_t)st.tok_off * 256, d, (size_t)st.n * 1024, kind, s));
+      if (on_device) { st.kp = k; st.desc = d; continue; }
+      st.kp = L->kpts + (size_t)st.tok_off * 2; st.desc = L->desc_tm + (size_t)st.tok_off * 256;
+      memcpy(L->h_stage + (size_t)st.tok_off * 2, k, (size_t)st.n * 8);
+      memcpy(L->h_stage + (size_t)L->ld * 2 + (size_t)st.tok_off * 256, d, (size_t)st.n * 1024);
     }
-  HIP_TRY(e, hipEventRecord(c->ev[0], s));
+  if (!on_device && T > 0) {
+    HIP_TRY(e, hipMemcpyAsync(L->kpts, L->h_stage, (size_t)T * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(L->desc_tm, L->h_stage + (size_t)L->ld * 2, (size_t)T * 1024, hipMemcpyHostToDevice, s));
+  }
+  memcpy(L->h_sets, L->last_sets.data(), sizeof(LgSet) * 2 * P);
+  HIP_TRY(e, hipMemcpyAsync(L->d_sets, L->h_sets, sizeof(LgSet) * 2 * P, hipMemcpyHostToDevice, s));
+  HIP_TRY(e, hipEventRecord(c->ev_lg0, s));
   const bool prof = e->profiling;
   if (max_n > 0) lg_forward(W, L, 2 * P, max_n, T, s, prof);
-  HIP_TRY(e, hipEventRecord(c->ev[1], s));
+  HIP_TRY(e, hipEventRecord(c->ev_lg1, s));
   HIP_TRY(e, hipGetLastError());
-  HIP_TRY(e, hipMemcpyAsync(L->h_m0, L->m0, (size_t)T * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(e, hipMemcpyAsync(L->h_m1, L->m1, (size_t)T * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(e, hipMemcpyAsync(L->h_max0, L->max0, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpy2DAsync(L->h_m0, (size_t)L->ld * 4, L->m0, (size_t)L->ld * 4, (size_t)T * 4, 3, hipMemcpyDeviceToHost, s));
+  if (t_overlap_fn) { (*t_overlap_fn)(); }   // host work of the caller that can run under the forward pass
   HIP_TRY(e, hipStreamSynchronize(s));
-  (void)hipEventElapsedTime(&c->ms[0], c->ev[0], c->ev[1]);
+  (void)hipEventElapsedTime(&c->ms[0], c->ev_lg0, c->ev_lg1);
   c->ms[4] = c->ms[0];
   t_last_ctx = c;
   if (prof && max_n > 0) {
@@ -1140,7 +1197,7 @@ int dani_lg_match(dani_engine* e, const float* kpts0, const float* desc0, int32_
 }
 
 int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches) {
-  LgContext* L = t_last_lg;
+  LgContext* L = last_lg(e);
   if (!e || !L) return DANI_ERR_INVALID;
   if (total_ms) *total_ms = L->attn_ms;
   if (total_flop) *total_flop = L->attn_flops;
@@ -1149,7 +1206,7 @@ int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flo
 }
 
 int dani_lg_debug_fetch(dani_engine* e, int32_t set, float* desc_out, int32_t* m0, float* max0, int32_t cap) {
-  LgContext* L = t_last_lg;
+  LgContext* L = last_lg(e);
   if (!e || !L || set < 0 || set >= (int)L->last_sets.size()) return fail(e, DANI_ERR_INVALID, "no previous LightGlue call on this thread");
   const LgSet& st = L->last_sets[set];
   if (st.n > cap) return fail(e, DANI_ERR_CAPACITY, "need %d", st.n);
@@ -1175,6 +1232,7 @@ namespace {
 
 constexpr int YOLO_W = 640, YOLO_H = 380;   // cv::resize(mRGB, img, cv::Size(640, 380)), src/YoloDetect.cpp:39
 constexpr int YOLO_CAND_CAP = 15120;
+constexpr int YOLO_CAND_FAST = 512;   // records per frame fetched together with the counts
 
 struct YConv { ConvLayerPlan plan; bool ready = false; };
 struct YoloWeights {
@@ -1192,7 +1250,6 @@ YoloWeights* yolo_weights(dani_engine* e) {
   return w;
 }
 
-struct YBuf { ActDesc a; };
 struct YoloContext {
   int B = 0;
   std::map<std::string, ActDesc> buf;
@@ -1202,6 +1259,21 @@ struct YoloContext {
   std::vector<void*> dev_allocs, host_allocs;
 };
 std::map<Context*, YoloContext*> g_yolo_ctx;
+
+void yolo_release(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (Context* c : e->ctxs) {
+    auto it = g_yolo_ctx.find(c);
+    if (it == g_yolo_ctx.end()) continue;
+    YoloContext* Y = it->second;
+    for (void* p : Y->dev_allocs) (void)hipFree(p);
+    for (void* p : Y->host_allocs) (void)hipHostFree(p);
+    delete Y;
+    g_yolo_ctx.erase(it);
+  }
+  auto w = g_yolo_w.find(e);
+  if (w != g_yolo_w.end()) { delete w->second; g_yolo_w.erase(w); }
+}
 
 void yolo_shape(ActDesc& a, int C, int H, int W, int pady) {
   a.C = C; a.H = H; a.W = W; a.pady = pady;
@@ -1423,6 +1495,12 @@ void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thres
 }
 
 thread_local YoloContext* t_last_yolo = nullptr;
+YoloContext* last_yolo(dani_engine* e) {
+  if (!e || !t_last_yolo) return nullptr;
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (Context* c : e->ctxs) { auto it = g_yolo_ctx.find(c); if (it != g_yolo_ctx.end() && it->second == t_last_yolo) return t_last_yolo; }
+  return nullptr;
+}
 
 }  // namespace
 
@@ -1455,14 +1533,22 @@ int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device
   yolo_forward(Wt, Y, B, score_thresh, s);
   HIP_TRY(e, hipEventRecord(c->ev_y1, s));
   HIP_TRY(e, hipGetLastError());
+  // read-back: the counts and, optimistically, the first YOLO_CAND_FAST records of every frame in one round trip;
+  // a frame with more candidates than that costs a second copy
   HIP_TRY(e, hipMemcpyAsync(Y->h_count, Y->cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpy2DAsync(Y->h_cand, (size_t)YOLO_CAND_CAP * 32, Y->cand, (size_t)YOLO_CAND_CAP * 32, (size_t)YOLO_CAND_FAST * 32, B,
+                              hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));
+  bool more = false;
   for (int b = 0; b < B; b++) {
     if (Y->h_count[b] > YOLO_CAND_CAP) Y->h_count[b] = YOLO_CAND_CAP;
-    if (Y->h_count[b])
-      HIP_TRY(e, hipMemcpyAsync(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->cand + (size_t)b * YOLO_CAND_CAP * 8, (size_t)Y->h_count[b] * 32, hipMemcpyDeviceToHost, s));
+    if (Y->h_count[b] > YOLO_CAND_FAST) {
+      more = true;
+      HIP_TRY(e, hipMemcpyAsync(Y->h_cand + ((size_t)b * YOLO_CAND_CAP + YOLO_CAND_FAST) * 8, Y->cand + ((size_t)b * YOLO_CAND_CAP + YOLO_CAND_FAST) * 8,
+                                (size_t)(Y->h_count[b] - YOLO_CAND_FAST) * 32, hipMemcpyDeviceToHost, s));
+    }
   }
-  HIP_TRY(e, hipStreamSynchronize(s));
+  if (more) HIP_TRY(e, hipStreamSynchronize(s));
   if (!t_alt_stream) { (void)hipEventElapsedTime(&c->ms[0], c->ev_y0, c->ev_y1); c->ms[4] = c->ms[0]; }
   int status = DANI_OK;
   // greedy NMS is O(k n) per frame and independent across frames
@@ -1489,8 +1575,8 @@ int dani_host_dynamic_areas(const float* dets6, int32_t n, int32_t cols, int32_t
 }
 
 int dani_yolo_debug_raw(dani_engine* e, int32_t b, int32_t level, float* out, int64_t count) {
-  YoloContext* Y = t_last_yolo;
-  Context* c = t_last_ctx;
+  YoloContext* Y = last_yolo(e);
+  Context* c = last_ctx(e);
   if (!e || !Y || !c || level < 0 || level > 2 || b < 0 || b >= Y->B || !out) return fail(e, DANI_ERR_INVALID, "bad argument");
   const char* raws[3] = {"raw0", "raw1", "raw2"};
   const ActDesc& a = Y->buf.at(raws[level]);
@@ -1534,6 +1620,14 @@ SeqState* seq_state(dani_engine* e, int id = 0) {
 }
 thread_local SeqState* t_last_seq = nullptr;
 
+void seq_release(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(g_seq_mu);
+  for (auto it = g_seq.begin(); it != g_seq.end();) {
+    if (it->first.first == e) { if (t_last_seq == it->second) t_last_seq = nullptr; delete it->second; it = g_seq.erase(it); }
+    else ++it;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1558,6 +1652,12 @@ int dani_frontend_reset(dani_engine* e, int32_t sequence) {
 
 int dani_frontend_timings(dani_engine* e, float* ms4) {
   if (!e || !ms4 || !t_last_seq) return DANI_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(g_seq_mu);
+    bool mine = false;
+    for (auto& kv : g_seq) mine = mine || (kv.first.first == e && kv.second == t_last_seq);
+    if (!mine) return DANI_ERR_INVALID;
+  }
   for (int i = 0; i < 4; i++) ms4[i] = t_last_seq->ms[i];
   return DANI_OK;
 }
@@ -1587,6 +1687,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     HIP_TRY(e, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(e, create_priority_stream(&c->stream2));
     (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
+    (void)hipEventCreate(&c->ev_lg0); (void)hipEventCreate(&c->ev_lg1);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     for (auto& ev : c->lev) (void)hipEventCreate(&ev);
     c->busy = true;   // never handed out by acquire()
@@ -1656,19 +1757,34 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
 
   // ---- 3. LightGlue: frame b-1 (query) vs frame b (train); slot 0 of the feature slabs = previous call's last frame
   const auto t2 = std::chrono::steady_clock::now();
+  // descriptor read-back: stream2 fills the pinned staging while LightGlue is being launched; the copy into the
+  // caller's array then runs on this thread under the forward pass
+  bool desc_moved = false;
+  std::function<void()> move_desc = [&] {
+    if (desc_moved || !desc) return;
+    desc_moved = true;
+    if (hipStreamSynchronize(c->stream2) != hipSuccess) return;
+    host_pool().run(B, [&](int b) {
+      if (n_out[b]) memcpy(desc + (size_t)b * cap * 256, c->h_desc + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024);
+    });
+  };
   if (p->match_previous) {
     std::vector<int32_t> n0(B), n1(B);
     for (int b = 0; b < B; b++) { n0[b] = b ? n_out[b - 1] : c->prev_n; n1[b] = n_out[b]; }
     const float sz[2] = {(float)W, (float)H};
+    t_overlap_fn = &move_desc;
     rc = dani_lg_match_batch(e, B, c->kcap, 1, c->d_kxy_all, c->d_desc_all, n0.data(), c->d_kxy, c->d_descout, n1.data(), sz, sz,
                              p->lg_threshold, matches, scores, match_cap, k_out);
-    if (rc) return rc;
+    t_overlap_fn = nullptr;
+    if (rc) { move_desc(); (void)hipStreamSynchronize(c->stream); return rc; }
   }
   // cache the last frame's features as the next call's predecessor
   HIP_TRY(e, hipMemcpyAsync(c->d_kxy_all, c->d_kxy + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+  move_desc();
   HIP_TRY(e, hipStreamSynchronize(c->stream));
-  HIP_TRY(e, hipStreamSynchronize(c->stream2));   // overlapped descriptor read-back
+  HIP_TRY(e, hipStreamSynchronize(c->stream2));
+  sp_read_timers(c, e->profiling);
   c->prev_n = n_out[B - 1];
   S->ms[2] = ms_since(t2);
   S->ms[3] = ms_since(t0);

@@ -218,8 +218,7 @@ void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, i
 // Learnable-Fourier positional encoding: proj = Wr (32x2) . kpt_n ; tables cos/sin [32][ld].
 // Also performs LightGlue::normalizeKeypoints (src/LightGlue.cpp:28-51): k = (k - size/2) / (max(size)/2).
 // ---------------------------------------------------------------------------------------------
-__global__ void posenc_kernel(const float* kpts /*[ld][2] token-major*/, const LgSet* sets, int nsets, const float* wr,
-                              float* cosb, float* sinb, int ld) {
+__global__ void posenc_kernel(const LgSet* sets, int nsets, const float* wr, float* cosb, float* sinb, int ld) {
   const int set = blockIdx.y;
   const LgSet st = sets[set];
   const int i = blockIdx.x * 64 + threadIdx.x;
@@ -228,7 +227,7 @@ __global__ void posenc_kernel(const float* kpts /*[ld][2] token-major*/, const L
   const float sx = st.size_w / 2.0f, sy = st.size_h / 2.0f;
   const float scale = fmaxf(st.size_w, st.size_h) / 2.0f;
   float x = 0.0f, y = 0.0f;
-  if (i < st.n) { x = (kpts[2 * tok] - sx) / scale; y = (kpts[2 * tok + 1] - sy) / scale; }
+  if (i < st.n) { x = (st.kp[2 * i] - sx) / scale; y = (st.kp[2 * i + 1] - sy) / scale; }
 #pragma unroll 4
   for (int f = 0; f < 32; f++) {
     const float p = wr[2 * f] * x + wr[2 * f + 1] * y;
@@ -237,13 +236,12 @@ __global__ void posenc_kernel(const float* kpts /*[ld][2] token-major*/, const L
   }
 }
 
-void launch_posenc(const float* kpts, const LgSet* sets, int nsets, int max_np, const float* wr, float* cosb,
-                   float* sinb, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(posenc_kernel, dim3((max_np + 63) / 64, nsets), dim3(64), 0, s, kpts, sets, nsets, wr, cosb, sinb, ld);
+void launch_posenc(const LgSet* sets, int nsets, int max_np, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(posenc_kernel, dim3((max_np + 63) / 64, nsets), dim3(64), 0, s, sets, nsets, wr, cosb, sinb, ld);
 }
 
-// token-major [tok][256] descriptors -> feature-major [256][ld] (zero for padding tokens)
-__global__ __launch_bounds__(256) void desc_to_fm_kernel(const float* desc_tm, const LgSet* sets, float* x, int ld) {
+// each set's token-major [n][256] descriptors (LgSet::desc) -> feature-major [256][ld] (zero for padding tokens)
+__global__ __launch_bounds__(256) void desc_to_fm_kernel(const LgSet* sets, float* x, int ld) {
   __shared__ float tile[64][65];
   const int set = blockIdx.z;
   const LgSet st = sets[set];
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(256) void desc_to_fm_kernel(const float* desc_tm, c
   const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
   for (int k = 0; k < 16; k++) {
     const int tl = rq + 4 * k, ti = t0 + tl;
-    tile[tl][c] = (ti < st.n) ? desc_tm[(size_t)(st.tok_off + ti) * 256 + f0 + c] : 0.0f;
+    tile[tl][c] = (ti < st.n) ? st.desc[(size_t)ti * 256 + f0 + c] : 0.0f;
   }
   __syncthreads();
   for (int k = 0; k < 16; k++) {
@@ -262,8 +260,8 @@ __global__ __launch_bounds__(256) void desc_to_fm_kernel(const float* desc_tm, c
   }
 }
 
-void launch_desc_to_fm(const float* desc_tm, const LgSet* sets, int nsets, int max_np, float* x, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(desc_to_fm_kernel, dim3((max_np + 63) / 64, 4, nsets), dim3(256), 0, s, desc_tm, sets, x, ld);
+void launch_desc_to_fm(const LgSet* sets, int nsets, int max_np, float* x, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(desc_to_fm_kernel, dim3((max_np + 63) / 64, 4, nsets), dim3(256), 0, s, sets, x, ld);
 }
 
 // ---------------------------------------------------------------------------------------------
