@@ -123,17 +123,32 @@ void launch_desc_best2(const float* q, const float* t, const int32_t* t_level, c
                        int32_t* best_level, int32_t* best_level2, hipStream_t s);
 
 // ---- LightGlue kernels (lg_kernels.hip) ------------------------------------------------------------
-// one keypoint set of a LightGlue batch; kp / desc point at the set's own token-major inputs ([n][2], [n][256]) so
-// that device-resident SuperPoint outputs are read in place (no gather copies)
-struct LgSet { int tok_off, n, partner_off, partner_n; float size_w, size_h; const float* kp; const float* desc; };
+// One keypoint set of a LightGlue batch.  Token layout of the transformer stage (all activations [features][ld]):
+//   main region  [tok_off, tok_off + round_up(nmain, 32))   keypoints 0 .. nmain-1 (+ zero padding)
+//   tail tokens  [tail_off, tail_off + n - nmain)            keypoints nmain .. n-1, packed after ALL main regions
+// A set whose count is a little over a multiple of 32 (n % 32 <= LG_TAIL_MAX, the quadtree's usual overshoot: 1024
+// requested -> 1025 returned) keeps only the multiple in its main region, so that one stray keypoint does not cost a
+// whole 32-query block / 32-key tile / 128-token GEMM tile per set; tail queries and keys are handled by VALU paths.
+// The assignment stage works on a dense copy (dense_off, padded to 32).  kp / desc point at the set's token-major
+// inputs ([n][2], [n][256]) so that device-resident SuperPoint outputs are read in place.
+constexpr int LG_TAIL_MAX = 4;
+struct LgSet {
+  int tok_off, n, nmain, tail_off;
+  int partner_off, partner_n, partner_nmain, partner_tail_off;
+  int dense_off;
+  float size_w, size_h;
+  const float* kp; const float* desc;
+};
 void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s);
 void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s);
-void launch_posenc(const LgSet* sets, int nsets, int max_np, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s);
-void launch_desc_to_fm(const LgSet* sets, int nsets, int max_np, float* x, int ld, hipStream_t s);
+void launch_posenc(const LgSet* sets, int nsets, int max_span, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s);
+void launch_desc_to_fm(const LgSet* sets, int nsets, int max_span, float* x, int ld, hipStream_t s);
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
-                      int max_n, int cross, float scale, hipStream_t s);
+                      int max_mp, int max_tail, int cross, float scale, hipStream_t s);
+void launch_lg_densify(const float* md, const float* logsig, const LgSet* sets, int nsets, int max_n, float* md_dense,
+                       float* logsig_dense, int ld, hipStream_t s);
 void launch_matchability(const float* x, const float* w, float b, float* logsig, int T, int ld, hipStream_t s);
 void launch_sim(const float* md, int ld, const LgSet* sets, int npairs, int max_np, float* sim, int sim_ld,
                 size_t sim_pair_stride, hipStream_t s);

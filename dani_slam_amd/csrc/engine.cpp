@@ -813,6 +813,7 @@ struct LgContext {
   LgSet* d_sets = nullptr;
   float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *msg = nullptr, *hbuf = nullptr, *qk = nullptr, *v = nullptr;
   float *cosb = nullptr, *sinb = nullptr, *md = nullptr, *logsig = nullptr, *lse_row = nullptr, *lse_col = nullptr, *max0 = nullptr;
+  float *md_dense = nullptr, *logsig_dense = nullptr;   // assignment stage: sets contiguous (LgSet::dense_off)
   int *m0 = nullptr, *m1 = nullptr;
   float* sim = nullptr;
   // pinned host
@@ -1004,11 +1005,11 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
   L->dev_allocs.clear(); L->host_allocs.clear();
   pairs = std::max(pairs, L->pairs); kmax = std::max(kmax, L->kmax);
   const int np = round_up(kmax, 32);
-  const int ld = round_up(pairs * 2 * np + 128, 256);
+  const int ld = round_up(pairs * 2 * np + round_up(pairs * 2 * LG_TAIL_MAX, 32) + 128, 256);   // main regions + shared tail region
   int rc;
 #define LGA(ptr, rows) if ((rc = lg_dev(e, L, (void**)&(ptr), (size_t)(rows) * ld * 4))) return rc;
   LGA(L->x, 256) LGA(L->qkv, 768) LGA(L->ctx, 256) LGA(L->msg, 256) LGA(L->hbuf, 512) LGA(L->qk, 256) LGA(L->v, 256)
-  LGA(L->cosb, 32) LGA(L->sinb, 32) LGA(L->md, 256) LGA(L->logsig, 1) LGA(L->lse_row, 1) LGA(L->lse_col, 1)
+  LGA(L->cosb, 32) LGA(L->sinb, 32) LGA(L->md, 256) LGA(L->logsig, 1) LGA(L->lse_row, 1) LGA(L->lse_col, 1) LGA(L->md_dense, 256) LGA(L->logsig_dense, 1)
   LGA(L->m0, 3) LGA(L->kpts, 2) LGA(L->desc_tm, 256)   // m0 | m1 | max0 are rows of one block: one read-back
   L->m1 = L->m0 + ld; L->max0 = reinterpret_cast<float*>(L->m0 + 2 * (size_t)ld);
 #undef LGA
@@ -1024,17 +1025,19 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
 }
 
 // the 9-layer forward + assignment statistics on stream s; the sets in L->d_sets point at their token-major inputs
-void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, hipStream_t s, bool prof) {
-  const int ld = L->ld, max_np = round_up(max_n, 32);
+struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T; };   // T = all main regions + the tail region
+
+void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof) {
+  const int ld = L->ld, nsets = sh.nsets, max_n = sh.max_n, T = sh.T, max_np = round_up(max_n, 32);
   if (prof && !L->aev_ready) { for (auto& ev : L->aev) (void)hipEventCreate(&ev); L->aev_ready = true; }
   int ai = 0;
   auto attn = [&](const float* Q, const float* K, const float* V, int cross, float scale) {
     if (prof) (void)hipEventRecord(L->aev[ai++], s);
-    launch_attention(Q, K, V, L->ctx, ld, L->d_sets, nsets, max_n, cross, scale, s);
+    launch_attention(Q, K, V, L->ctx, ld, L->d_sets, nsets, sh.max_mp, sh.max_tail, cross, scale, s);
     if (prof) (void)hipEventRecord(L->aev[ai++], s);
   };
-  launch_desc_to_fm(L->d_sets, nsets, max_np, L->x, ld, s);
-  launch_posenc(L->d_sets, nsets, max_np, W->wr, L->cosb, L->sinb, ld, s);
+  launch_desc_to_fm(L->d_sets, nsets, sh.max_span, L->x, ld, s);
+  launch_posenc(L->d_sets, nsets, sh.max_span, W->wr, L->cosb, L->sinb, ld, s);
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
     launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
   };
@@ -1056,8 +1059,9 @@ void lg_forward(const LgWeights* W, LgContext* L, int nsets, int max_n, int T, h
   lin(W->final_proj, L->x, 256, nullptr, 0, L->md, nullptr, 0, 0.25f);   // / d^0.25, d = 256
   launch_matchability(L->x, W->match_w, W->match_b, L->logsig, T, ld, s);
   const size_t pstride = (size_t)(round_up(L->kmax, 32) + 64) * L->sim_ld;
-  launch_sim(L->md, ld, L->d_sets, nsets / 2, max_np, L->sim, L->sim_ld, pstride, s);
-  launch_assignment_stats(L->sim, L->sim_ld, pstride, L->d_sets, nsets / 2, max_n, L->logsig, L->lse_row, L->lse_col,
+  launch_lg_densify(L->md, L->logsig, L->d_sets, nsets, max_n, L->md_dense, L->logsig_dense, ld, s);
+  launch_sim(L->md_dense, ld, L->d_sets, nsets / 2, max_np, L->sim, L->sim_ld, pstride, s);
+  launch_assignment_stats(L->sim, L->sim_ld, pstride, L->d_sets, nsets / 2, max_n, L->logsig_dense, L->lse_row, L->lse_col,
                           L->m0, L->max0, L->m1, ld, s);
 }
 
@@ -1097,17 +1101,32 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
   if (rc) return rc;
   t_last_lg = L;
   hipStream_t s = c->stream;
-  // token layout: set 2p = side 0 of pair p, set 2p+1 = side 1; each padded to a multiple of 32 tokens
-  int off = 0, max_n = 0;
+  // token layout (common.h, LgSet): set 2p = side 0 of pair p, set 2p+1 = side 1.  Main regions first, each padded to a
+  // multiple of 32 tokens; then the shared tail region; the dense layout of the assignment stage pads every set to 32.
+  int off = 0, doff = 0, ntail = 0, max_n = 0;
+  LgShape sh{2 * P, 0, 0, 0, 0, 0};
   L->last_sets.assign(2 * P, LgSet());
+  auto place = [&](LgSet& a, int n) {
+    const int t = n % 32;
+    a.n = n; a.nmain = (n >= 32 && t > 0 && t <= LG_TAIL_MAX) ? n - t : n;
+    a.tok_off = off; off += round_up(std::max(a.nmain, 1), 32);
+    a.dense_off = doff; doff += round_up(std::max(n, 1), 32);
+    a.tail_off = ntail; ntail += n - a.nmain;            // relative to the tail region for now
+    max_n = std::max(max_n, n);
+    sh.max_mp = std::max(sh.max_mp, round_up(a.nmain, 32));
+    sh.max_span = std::max(sh.max_span, round_up(a.nmain, 32) + (n - a.nmain));
+    sh.max_tail = std::max(sh.max_tail, n - a.nmain);
+  };
+  for (int p = 0; p < P; p++) { place(L->last_sets[2 * p], n0[p]); place(L->last_sets[2 * p + 1], n1[p]); }
+  const int T_main = off;
+  for (LgSet& a : L->last_sets) a.tail_off += T_main;
   for (int p = 0; p < P; p++) {
     LgSet& a = L->last_sets[2 * p]; LgSet& b = L->last_sets[2 * p + 1];
-    a.tok_off = off; a.n = n0[p]; off += round_up(std::max(n0[p], 1), 32);
-    b.tok_off = off; b.n = n1[p]; off += round_up(std::max(n1[p], 1), 32);
-    a.partner_off = b.tok_off; a.partner_n = b.n; b.partner_off = a.tok_off; b.partner_n = a.n;
-    max_n = std::max(max_n, std::max(a.n, b.n));
+    a.partner_off = b.tok_off; a.partner_n = b.n; a.partner_nmain = b.nmain; a.partner_tail_off = b.tail_off;
+    b.partner_off = a.tok_off; b.partner_n = a.n; b.partner_nmain = a.nmain; b.partner_tail_off = a.tail_off;
   }
-  const int T = off;
+  const int T = T_main + round_up(ntail, 32);
+  sh.max_n = max_n; sh.T = T;
   // sizes: explicit (w,h) or 1 + max - min of the keypoints (needs host keypoints)
   std::vector<float> hk;
   auto host_kpts = [&](const float* k, int p, int n) -> const float* {
@@ -1135,22 +1154,25 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
       const float* k = (side ? kpts1 : kpts0) + (size_t)p * in_cap * 2;
       const float* d = (side ? desc1 : desc0) + (size_t)p * in_cap * 256;
       if (on_device) { st.kp = k; st.desc = d; continue; }
-      st.kp = L->kpts + (size_t)st.tok_off * 2; st.desc = L->desc_tm + (size_t)st.tok_off * 256;
-      memcpy(L->h_stage + (size_t)st.tok_off * 2, k, (size_t)st.n * 8);
-      memcpy(L->h_stage + (size_t)L->ld * 2 + (size_t)st.tok_off * 256, d, (size_t)st.n * 1024);
+      st.kp = L->kpts + (size_t)st.dense_off * 2; st.desc = L->desc_tm + (size_t)st.dense_off * 256;
+      memcpy(L->h_stage + (size_t)st.dense_off * 2, k, (size_t)st.n * 8);
+      memcpy(L->h_stage + (size_t)L->ld * 2 + (size_t)st.dense_off * 256, d, (size_t)st.n * 1024);
     }
-  if (!on_device && T > 0) {
-    HIP_TRY(e, hipMemcpyAsync(L->kpts, L->h_stage, (size_t)T * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(e, hipMemcpyAsync(L->desc_tm, L->h_stage + (size_t)L->ld * 2, (size_t)T * 1024, hipMemcpyHostToDevice, s));
+  if (!on_device && doff > 0) {
+    HIP_TRY(e, hipMemcpyAsync(L->kpts, L->h_stage, (size_t)doff * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(L->desc_tm, L->h_stage + (size_t)L->ld * 2, (size_t)doff * 1024, hipMemcpyHostToDevice, s));
   }
+  // padding columns of the tail region: keep the residual stream finite there (they are never read as keys)
+  if (T > T_main + ntail)
+    HIP_TRY(e, hipMemset2DAsync(L->x + T_main + ntail, (size_t)L->ld * 4, 0, (size_t)(T - T_main - ntail) * 4, 256, s));
   memcpy(L->h_sets, L->last_sets.data(), sizeof(LgSet) * 2 * P);
   HIP_TRY(e, hipMemcpyAsync(L->d_sets, L->h_sets, sizeof(LgSet) * 2 * P, hipMemcpyHostToDevice, s));
   HIP_TRY(e, hipEventRecord(c->ev_lg0, s));
   const bool prof = e->profiling;
-  if (max_n > 0) lg_forward(W, L, 2 * P, max_n, T, s, prof);
+  if (max_n > 0) lg_forward(W, L, sh, s, prof);
   HIP_TRY(e, hipEventRecord(c->ev_lg1, s));
   HIP_TRY(e, hipGetLastError());
-  HIP_TRY(e, hipMemcpy2DAsync(L->h_m0, (size_t)L->ld * 4, L->m0, (size_t)L->ld * 4, (size_t)T * 4, 3, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpy2DAsync(L->h_m0, (size_t)L->ld * 4, L->m0, (size_t)L->ld * 4, (size_t)doff * 4, 3, hipMemcpyDeviceToHost, s));
   if (t_overlap_fn) { (*t_overlap_fn)(); }   // host work of the caller that can run under the forward pass
   HIP_TRY(e, hipStreamSynchronize(s));
   (void)hipEventElapsedTime(&c->ms[0], c->ev_lg0, c->ev_lg1);
@@ -1173,9 +1195,9 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
     float* so = scores + (size_t)p * cap;
     if (a.n > 0 && b.n > 0)
       for (int i = 0; i < a.n; i++) {
-        const int jj = L->h_m0[a.tok_off + i];
-        if (jj < 0 || jj >= b.n || L->h_m1[b.tok_off + jj] != i) continue;
-        const float ms = std::exp(L->h_max0[a.tok_off + i]);
+        const int jj = L->h_m0[a.dense_off + i];
+        if (jj < 0 || jj >= b.n || L->h_m1[b.dense_off + jj] != i) continue;
+        const float ms = std::exp(L->h_max0[a.dense_off + i]);
         if (!(ms > 0.1f) || !(ms > threshold)) continue;
         if (k < cap) { mo[2 * k] = i; mo[2 * k + 1] = jj; so[k] = ms; }
         k++;
@@ -1213,13 +1235,16 @@ int dani_lg_debug_fetch(dani_engine* e, int32_t set, float* desc_out, int32_t* m
   HIP_TRY(e, hipSetDevice(e->device));
   if (desc_out) {
     std::vector<float> tmp((size_t)256 * st.n);
-    for (int f = 0; f < 256; f++)
-      HIP_TRY(e, hipMemcpy(&tmp[(size_t)f * st.n], L->x + (size_t)f * L->ld + st.tok_off, (size_t)st.n * 4, hipMemcpyDeviceToHost));
+    for (int f = 0; f < 256; f++) {
+      HIP_TRY(e, hipMemcpy(&tmp[(size_t)f * st.n], L->x + (size_t)f * L->ld + st.tok_off, (size_t)st.nmain * 4, hipMemcpyDeviceToHost));
+      if (st.n > st.nmain)
+        HIP_TRY(e, hipMemcpy(&tmp[(size_t)f * st.n + st.nmain], L->x + (size_t)f * L->ld + st.tail_off, (size_t)(st.n - st.nmain) * 4, hipMemcpyDeviceToHost));
+    }
     for (int i = 0; i < st.n; i++)
       for (int f = 0; f < 256; f++) desc_out[(size_t)i * 256 + f] = tmp[(size_t)f * st.n + i];
   }
-  if (m0) memcpy(m0, L->h_m0 + st.tok_off, (size_t)st.n * 4);
-  if (max0) memcpy(max0, L->h_max0 + st.tok_off, (size_t)st.n * 4);
+  if (m0) memcpy(m0, L->h_m0 + st.dense_off, (size_t)st.n * 4);
+  if (max0) memcpy(max0, L->h_max0 + st.dense_off, (size_t)st.n * 4);
   return DANI_OK;
 }
 

@@ -13,6 +13,11 @@
 //     16 in-lane ops + one shfl_xor 32), and the probabilities in the S^T accumulator ARE the B operand of the
 //     O^T = V^T P^T product register for register (no LDS round trip, no transposes).
 // All contractions use v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate); bound: MFMA.
+//
+// Ragged sets: a set with n = 32k + t keypoints, t <= LG_TAIL_MAX, keeps 32k tokens in its main region and its t tail
+// tokens in a region shared by all sets (common.h, LgSet).  The quadtree returns one or two keypoints more than asked
+// for, and with whole-block padding that single keypoint cost every launch a third, almost empty round of workgroups
+// (1088 instead of 1024 on 512 slots: attention 193 us instead of 150 us per launch at 16 x 1025 keypoints).
 #include "common.h"
 
 namespace dani {
@@ -21,6 +26,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // linear_fm_kernel:  Y[o][t] = epilogue( sum_k W[o][k] * X[k][t] + b[o] ),  X = concat(X0 rows, X1 rows).
@@ -53,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   float* sX = lds;
   float* sW = lds + KC * TT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-  const int tok0 = blockIdx.x * TT, ot = blockIdx.y;
+  const int tok0 = (gridDim.x - 1 - blockIdx.x) * TT, ot = blockIdx.y;
   const int K = a.K0 + a.K1, nchunks = K / KC;
   const float* wt = a.w + (size_t)ot * K * LIN_NCO;
   const int wtok = (TT >= 128) ? wave * (TT / 4) : (wave & 1) * 32;   // wave's first token inside the tile
@@ -154,6 +169,8 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   }
 }
 
+int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = heuristic below)
+
 void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s) {
@@ -161,10 +178,12 @@ void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w_packed; a.bias = bias_packed; a.y = y; a.res = res;
   a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;
   const int otiles = (OUT + LIN_NCO - 1) / LIN_NCO;
-  // largest token tile that still yields >= 4 workgroups per CU; else the smallest (load balance beats reuse)
+  // Largest token tile that still yields >= 16 workgroups per CU, else the smallest: measured on the LightGlue shapes
+  // (tools/probes/lin_bench.hip, 16 x 1025 keypoints) the 64-token tile -- 86 VGPRs, 32 KB LDS, 5 workgroups per CU --
+  // beats the 128-token one (121 VGPRs, 48 KB, 3 per CU) by 9-15 % until the grid is several rounds deep.
   auto wgs = [&](int tt) { return ((T + tt - 1) / tt) * otiles; };
-  if (wgs(256) >= 1024) hipLaunchKernelGGL(linear_fm_kernel<256>, dim3((T + 255) / 256, otiles), dim3(256), 0, s, a);
-  else if (wgs(128) >= 1024) hipLaunchKernelGGL(linear_fm_kernel<128>, dim3((T + 127) / 128, otiles), dim3(256), 0, s, a);
+  if (g_lin_force_tt == 256 || (!g_lin_force_tt && wgs(256) >= 4096)) hipLaunchKernelGGL(linear_fm_kernel<256>, dim3((T + 255) / 256, otiles), dim3(256), 0, s, a);
+  else if (g_lin_force_tt == 128 || (!g_lin_force_tt && wgs(128) >= 4096)) hipLaunchKernelGGL(linear_fm_kernel<128>, dim3((T + 127) / 128, otiles), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(linear_fm_kernel<64>, dim3((T + 63) / 64, otiles), dim3(256), 0, s, a);
 }
 
@@ -221,13 +240,16 @@ void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, i
 __global__ void posenc_kernel(const LgSet* sets, int nsets, const float* wr, float* cosb, float* sinb, int ld) {
   const int set = blockIdx.y;
   const LgSet st = sets[set];
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= ((st.n + 31) & ~31)) return;
-  const int tok = st.tok_off + i;
+  const int i = blockIdx.x * 64 + threadIdx.x;   // position in the set's span: padded main region, then tail tokens
+  const int mp = (st.nmain + 31) & ~31, nt = st.n - st.nmain;
+  int tok, kpi = -1;
+  if (i < mp) { tok = st.tok_off + i; if (i < st.nmain) kpi = i; }
+  else if (i - mp < nt) { tok = st.tail_off + (i - mp); kpi = st.nmain + (i - mp); }
+  else return;
   const float sx = st.size_w / 2.0f, sy = st.size_h / 2.0f;
   const float scale = fmaxf(st.size_w, st.size_h) / 2.0f;
   float x = 0.0f, y = 0.0f;
-  if (i < st.n) { x = (st.kp[2 * i] - sx) / scale; y = (st.kp[2 * i + 1] - sy) / scale; }
+  if (kpi >= 0) { x = (st.kp[2 * kpi] - sx) / scale; y = (st.kp[2 * kpi + 1] - sy) / scale; }
 #pragma unroll 4
   for (int f = 0; f < 32; f++) {
     const float p = wr[2 * f] * x + wr[2 * f + 1] * y;
@@ -236,8 +258,8 @@ __global__ void posenc_kernel(const LgSet* sets, int nsets, const float* wr, flo
   }
 }
 
-void launch_posenc(const LgSet* sets, int nsets, int max_np, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(posenc_kernel, dim3((max_np + 63) / 64, nsets), dim3(64), 0, s, sets, nsets, wr, cosb, sinb, ld);
+void launch_posenc(const LgSet* sets, int nsets, int max_span, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(posenc_kernel, dim3((max_span + 63) / 64, nsets), dim3(64), 0, s, sets, nsets, wr, cosb, sinb, ld);
 }
 
 // each set's token-major [n][256] descriptors (LgSet::desc) -> feature-major [256][ld] (zero for padding tokens)
@@ -245,23 +267,31 @@ __global__ __launch_bounds__(256) void desc_to_fm_kernel(const LgSet* sets, floa
   __shared__ float tile[64][65];
   const int set = blockIdx.z;
   const LgSet st = sets[set];
-  const int np = (st.n + 31) & ~31;
-  const int t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
-  if (t0 >= np) return;
+  const int mp = (st.nmain + 31) & ~31, nt = st.n - st.nmain;
+  const int t0 = blockIdx.x * 64, f0 = blockIdx.y * 64;   // t0: position in the span (padded main region, then tail)
+  if (t0 >= mp + nt) return;
   const int c = threadIdx.x & 63, rq = threadIdx.x >> 6;
   for (int k = 0; k < 16; k++) {
     const int tl = rq + 4 * k, ti = t0 + tl;
-    tile[tl][c] = (ti < st.n) ? st.desc[(size_t)ti * 256 + f0 + c] : 0.0f;
+    int kpi = -1;
+    if (ti < mp) { if (ti < st.nmain) kpi = ti; }
+    else if (ti - mp < nt) kpi = st.nmain + (ti - mp);
+    tile[tl][c] = (kpi >= 0) ? st.desc[(size_t)kpi * 256 + f0 + c] : 0.0f;
   }
   __syncthreads();
+  const int ti = t0 + c;
+  int tok = -1;
+  if (ti < mp) tok = st.tok_off + ti;
+  else if (ti - mp < nt) tok = st.tail_off + (ti - mp);
+  if (tok < 0) return;
   for (int k = 0; k < 16; k++) {
-    const int fl = rq + 4 * k, ti = t0 + c;
-    if (ti < np) x[(size_t)(f0 + fl) * ld + st.tok_off + ti] = tile[c][fl];
+    const int fl = rq + 4 * k;
+    x[(size_t)(f0 + fl) * ld + tok] = tile[c][fl];
   }
 }
 
-void launch_desc_to_fm(const LgSet* sets, int nsets, int max_np, float* x, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(desc_to_fm_kernel, dim3((max_np + 63) / 64, 4, nsets), dim3(256), 0, s, sets, x, ld);
+void launch_desc_to_fm(const LgSet* sets, int nsets, int max_span, float* x, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(desc_to_fm_kernel, dim3((max_span + 63) / 64, 4, nsets), dim3(256), 0, s, sets, x, ld);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,26 +302,154 @@ void launch_desc_to_fm(const LgSet* sets, int nsets, int max_np, float* x, int l
 // ---------------------------------------------------------------------------------------------
 constexpr int AT_STRIDE = 33;
 
+// Workgroup roles of an attention launch with tail queries: the grid has `tail_slots` extra blockIdx.x values per
+// (head, set), one per tail query; the linear workgroup id (dispatch order) is re-read so that ALL main tiles come
+// first -- their count fills the chip's slots in whole rounds -- and the short tail-query workgroups run last, on the
+// CUs that finish first.  Returns the tail query index, or -1 for a main tile (bx = its query tile).
+__device__ __forceinline__ int attn_role(int tail_slots, int& bx, int& by, int& bz) {
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  if (!tail_slots) return -1;
+  const int gx = gridDim.x - tail_slots, gy = gridDim.y;
+  const int L = blockIdx.x + gridDim.x * (blockIdx.y + gy * blockIdx.z), nmain = gx * gy * gridDim.z;
+  if (L < nmain) { bx = L % gx; by = (L / gx) % gy; bz = L / (gx * gy); return -1; }
+  const int t = L - nmain;
+  bx = 0; by = (t / tail_slots) % gy; bz = t / (tail_slots * gy);
+  return t % tail_slots;
+}
+
+// key side of a (query set, key set) pair
+struct AttnKeys { int off, n, nmain, tail_off; };
+__device__ __forceinline__ AttnKeys attn_keys(const LgSet& st, int cross) {
+  AttnKeys k;
+  k.off = cross ? st.partner_off : st.tok_off; k.n = cross ? st.partner_n : st.n;
+  k.nmain = cross ? st.partner_nmain : st.nmain; k.tail_off = cross ? st.partner_tail_off : st.tail_off;
+  return k;
+}
+
+// The key set's tail keys (at most LG_TAIL_MAX), folded into a 32-query wave's online-softmax state on the VALU:
+// one key costs ~130 VALU/LDS ops against the 64 MFMAs of a whole key tile.  Their K / V columns are staged once per
+// workgroup in LDS (`tk`: [key][K 64 | V 64], loaded with the query prologue); every read below is a broadcast.
+// qreg / o / m / l as in the MFMA loop (base-2 logits; lane (j, h) holds query j, the d = 2t + h half of q and the
+// acc_row(r, h) rows of O^T).
+__device__ __forceinline__ void attn_stage_tail_keys(const float* Kh, const float* Vh, int ld, int ktok0, int nt, float* tk) {
+  for (int e = threadIdx.x; e < nt * 128; e += blockDim.x) {
+    const int key = e >> 7, c = e & 127;
+    tk[e] = (c < 64 ? Kh : Vh)[(size_t)(c & 63) * ld + ktok0 + key];
+  }
+}
+__device__ __forceinline__ void attn_tail_keys(const float* tk, int nt, const float (&qreg)[32], f32x16 (&o)[2], float& m, float& l,
+                                               int h) {
+  for (int k = 0; k < nt; k++) {
+    const float* kc = tk + k * 128;
+    float sp = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 32; t++) sp = fmaf(qreg[t], kc[2 * t + h], sp);
+    const float sv = sp + __shfl_xor(sp, 32);
+    const float m_new = fmaxf(m, sv);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new), pr = __builtin_amdgcn_exp2f(sv - m_new);
+    l = l * alpha + (h == 0 ? pr : 0.0f);          // l is a per-half partial sum: count the key once
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      o[0][r] = fmaf(pr, kc[64 + acc_row(r, h)], o[0][r] * alpha);
+      o[1][r] = fmaf(pr, kc[96 + acc_row(r, h)], o[1][r] * alpha);
+    }
+    m = m_new;
+  }
+}
+
+// One tail query of a set (at most LG_TAIL_MAX per set), all VALU: keys on the lanes, the workgroup's waves take the
+// 64-key chunks round-robin (K and V columns loaded in batches of 64 independent loads) and their partial (m, l, O)
+// states are merged through LDS (`xch`, >= nw * 66 floats).  These workgroups run LAST in the attention launch
+// (attn_role), one per (tail query, head, set), ~15 us each on a chip that is emptying.
+__device__ __forceinline__ void attn_tail_query(const float* Q, const float* K, const float* V, float* O, int ld,
+                                                const LgSet& st, int qi, int head, int cross, float scale, float* xch) {
+  if (qi >= st.n - st.nmain) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const AttnKeys ks = attn_keys(st, cross);
+  const float* Kh = K + (size_t)head * 64 * ld;
+  const float* Vh = V + (size_t)head * 64 * ld;
+  {
+    const int qt = st.tail_off + qi;
+    const int qbits = __float_as_int(Q[(size_t)(head * 64 + lane) * ld + qt] * (scale * 1.44269504088896341f));   // lane = d
+    float o[64];
+#pragma unroll
+    for (int d = 0; d < 64; d++) o[d] = 0.0f;
+    float m = -1e30f, l = 0.0f;
+    for (int k0 = wave * 64; k0 < ks.n; k0 += nw * 64) {
+      const int key = k0 + lane;
+      const bool valid = key < ks.n;
+      const int kk = min(key, ks.n - 1);
+      const int tok = kk < ks.nmain ? ks.off + kk : ks.tail_off + (kk - ks.nmain);
+      float col[64];
+#pragma unroll
+      for (int d = 0; d < 64; d++) col[d] = Kh[(size_t)d * ld + tok];
+      float sv = 0.0f;
+#pragma unroll
+      for (int d = 0; d < 64; d++) sv = fmaf(__int_as_float(__builtin_amdgcn_readlane(qbits, d)), col[d], sv);
+#pragma unroll
+      for (int d = 0; d < 64; d++) col[d] = Vh[(size_t)d * ld + tok];
+      if (!valid) sv = -1e30f;
+      const float m_new = fmaxf(m, sv);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new), pr = valid ? __builtin_amdgcn_exp2f(sv - m_new) : 0.0f;
+      l = l * alpha + pr;
+#pragma unroll
+      for (int d = 0; d < 64; d++) o[d] = fmaf(pr, col[d], o[d] * alpha);
+      m = m_new;
+    }
+    // wave-level reduction: lane d ends up with O[d] of this wave's keys
+    const float M = wave_max(m);
+    const float w = __builtin_amdgcn_exp2f(m - M);
+    const float Lw = wave_sumf(l * w);
+    float out = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 64; d++) {
+      const float tot = wave_sumf(o[d] * w);
+      if (lane == d) out = tot;
+    }
+    xch[wave * 66 + lane] = out;
+    if (lane == 0) { xch[wave * 66 + 64] = M; xch[wave * 66 + 65] = Lw; }
+    __syncthreads();
+    if (wave == 0) {
+      float MM = -1e30f;
+      for (int k = 0; k < nw; k++) MM = fmaxf(MM, xch[k * 66 + 64]);
+      float acc = 0.0f, LL = 0.0f;
+      for (int k = 0; k < nw; k++) {
+        const float f = __builtin_amdgcn_exp2f(xch[k * 66 + 64] - MM);
+        acc += xch[k * 66 + lane] * f; LL += xch[k * 66 + 65] * f;
+      }
+      O[(size_t)(head * 64 + lane) * ld + qt] = LL > 0.0f ? acc / LL : 0.0f;
+    }
+  }
+}
+
 template <int NW>   // waves (= 32-query blocks) per workgroup
 __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
-                                                          const LgSet* sets, int cross, float scale) {
+                                                          const LgSet* sets, int tail_slots, int cross, float scale) {
   __shared__ float sK[64 * AT_STRIDE];
   __shared__ float sV[64 * AT_STRIDE];
-  const LgSet st = sets[blockIdx.z];
-  const int q0 = blockIdx.x * (32 * NW);
-  if (q0 >= ((st.n + 31) & ~31)) return;
-  const int head = blockIdx.y;
+  __shared__ float sTK[LG_TAIL_MAX * 128];
+  int bx, head, bz;
+  const int tail_q = attn_role(tail_slots, bx, head, bz);
+  const LgSet st = sets[bz];
+  if (tail_q >= 0) { attn_tail_query(Q, K, V, O, ld, st, tail_q, head, cross, scale, sK); return; }
+  const int mp = (st.nmain + 31) & ~31;
+  const int q0 = bx * (32 * NW);
+  if (q0 >= mp) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-  const int k_off = cross ? st.partner_off : st.tok_off, k_n = cross ? st.partner_n : st.n;
-  const int qi = q0 + wave * 32 + j;                       // may exceed n (padding rows: computed, not stored)
-  const int qtok = st.tok_off + min(qi, ((st.n + 31) & ~31) - 1);
+  const AttnKeys ks = attn_keys(st, cross);
+  const int k_off = ks.off, k_n = ks.nmain;                // the MFMA loop covers the key set's main region
+  const int qi = q0 + wave * 32 + j;                       // may exceed nmain (padding rows: computed, not stored)
+  const int qtok = st.tok_off + min(qi, mp - 1);
   const float* Qh = Q + (size_t)head * 64 * ld;
   const float* Kh = K + (size_t)head * 64 * ld + k_off;
   const float* Vh = V + (size_t)head * 64 * ld + k_off;
+  if (ks.n > ks.nmain)   // visible to all waves after the first barrier of the tile loop
+    attn_stage_tail_keys(K + (size_t)head * 64 * ld, V + (size_t)head * 64 * ld, ld, ks.tail_off, ks.n - ks.nmain, sTK);
 
   float qreg[32];
 #pragma unroll
-  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * scale;
+  // softmax runs in base 2: log2(e) is folded into the query scale so that exp() is a bare v_exp_f32
+  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * (scale * 1.44269504088896341f);
 
   f32x16 o[2];
 #pragma unroll
@@ -345,10 +503,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const float* Q, const 
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m, mx);
-    const float alpha = __expf(m - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     float ls = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; r++) { s[r] = __expf(s[r] - m_new); ls += s[r]; }
+    for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ls += s[r]; }
     l = l * alpha + ls;
     m = m_new;
 #pragma unroll
@@ -362,17 +520,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const float* Q, const 
     }
   }
 #undef AT_PREFETCH
+  if (ks.n > ks.nmain) {
+    if (ntiles == 0) __syncthreads();   // no tile loop ran: make the staged tail keys visible
+    attn_tail_keys(sTK, ks.n - ks.nmain, qreg, o, m, l, h);
+  }
   const float lt = l + __shfl_xor(l, 32);
   const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;            // empty key set -> zero message
-  // padding queries (n <= qi < padded n) get zeros so that every column of the set stays finite: masked keys are
-  // multiplied by p = 0 in later layers, and 0 * NaN would poison valid rows
-  if (qi < ((st.n + 31) & ~31)) {
-    const float keep = qi < st.n ? inv : 0.0f;
+  // padding queries (nmain <= qi < padded nmain) get zeros so that every column of the set stays finite: masked keys
+  // are multiplied by p = 0 in later layers, and 0 * NaN would poison valid rows
+  if (qi < mp) {
+    const float keep = qi < st.nmain ? inv : 0.0f;
     float* Oh = O + (size_t)head * 64 * ld + st.tok_off + qi;
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) Oh[(size_t)(db * 32 + acc_row(r, h)) * ld] = qi < st.n ? o[db][r] * keep : 0.0f;
+      for (int r = 0; r < 16; r++) Oh[(size_t)(db * 32 + acc_row(r, h)) * ld] = qi < st.nmain ? o[db][r] * keep : 0.0f;
   }
 }
 
@@ -384,16 +546,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const float* Q, const 
 // (82 %).  The two query blocks share every staged K/V tile.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
-                                                         const LgSet* sets, int cross, float scale) {
+                                                         const LgSet* sets, int tail_slots, int cross, float scale) {
   __shared__ float sKV[4 * 64 * AT_STRIDE];   // [key half][K | V][64 d][33]
-  const LgSet st = sets[blockIdx.z];
-  const int np = (st.n + 31) & ~31;
-  const int q0 = blockIdx.x * 64;
+  __shared__ float sTK[LG_TAIL_MAX * 128];
+  int bx, head, bz;
+  const int tail_q = attn_role(tail_slots, bx, head, bz);
+  const LgSet st = sets[bz];
+  if (tail_q >= 0) { attn_tail_query(Q, K, V, O, ld, st, tail_q, head, cross, scale, sKV); return; }
+  const int np = (st.nmain + 31) & ~31;                    // queries of the main region
+  const int q0 = bx * 64;
   if (q0 >= np) return;
-  const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
   const int qb = wave & 1, kh = wave >> 1;
-  const int k_off = cross ? st.partner_off : st.tok_off, k_n = cross ? st.partner_n : st.n;
+  const AttnKeys ks = attn_keys(st, cross);
+  const int k_off = ks.off, k_n = ks.nmain;                // the MFMA loop covers the key set's main region
   const int qi = q0 + qb * 32 + j;
   const bool wave_active = (q0 + qb * 32) < np;              // wave-uniform: the last tile may hold one block only
   const int qtok = st.tok_off + min(qi, np - 1);
@@ -402,6 +568,8 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
   const float* Vh = V + (size_t)head * 64 * ld + k_off;
   float* sK = sKV + (size_t)kh * 2 * 64 * AT_STRIDE;
   float* sV = sK + 64 * AT_STRIDE;
+  if (ks.n > ks.nmain)   // visible to all waves after the first barrier of the tile loop
+    attn_stage_tail_keys(K + (size_t)head * 64 * ld, V + (size_t)head * 64 * ld, ld, ks.tail_off, ks.n - ks.nmain, sTK);
 
   float qreg[32];
 #pragma unroll
@@ -426,10 +594,11 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
     hsel[u] = hh * half;
   }
   // a key half may hold one tile fewer than the other: its extra load is clamped to the last tile and never used
+  // (and to tile 0 for an empty key set, whose padded region is still 32 tokens wide)
 #define ATK_PREFETCH(it_)                                                                          \
   {                                                                                                \
     _Pragma("unroll") for (int u = 0; u < 8; u++)                                                  \
-      pf[u] = *reinterpret_cast<const f32x4*>(gsrc[u] + min(hsel[u] + (it_), ntiles - 1) * 32);    \
+      pf[u] = *reinterpret_cast<const f32x4*>(gsrc[u] + max(min(hsel[u] + (it_), ntiles - 1), 0) * 32); \
   }
   ATK_PREFETCH(0);
   for (int it = 0; it < half; it++) {
@@ -479,6 +648,10 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
     }
   }
 #undef ATK_PREFETCH
+  if (ks.n > ks.nmain) {                                  // the (shorter) second key half also takes the tail keys
+    if (half == 0) __syncthreads();                       // no tile loop ran: make the staged tail keys visible
+    if (kh == 1 && wave_active) attn_tail_keys(sTK, ks.n - ks.nmain, qreg, o, m, l, h);
+  }
   // ---- merge the two key halves of each query block through LDS (reusing the tile buffers)
   __syncthreads();
   float* xch = sKV + (size_t)qb * (64 * 34);           // per query block: 64 lanes x 34 floats
@@ -496,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
     const float a0 = __builtin_amdgcn_exp2f(m - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
     const float lt0 = l * a0 + l1 * a1;
     const float lt = lt0 + __shfl_xor(lt0, 32);
-    const float inv = (lt > 0.0f && qi < st.n) ? 1.0f / lt : 0.0f;    // padding queries and empty key sets -> 0
+    const float inv = (lt > 0.0f && qi < st.nmain) ? 1.0f / lt : 0.0f;   // padding queries and empty key sets -> 0
     float* Oh = O + (size_t)head * 64 * ld + st.tok_off + qi;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -507,12 +680,12 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
 }
 
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
-                      int max_n, int cross, float scale, hipStream_t s) {
-  const int max_np = (max_n + 31) & ~31;
-  if (((max_np + 127) / 128) * 4 * nsets >= 1024)
-    hipLaunchKernelGGL(attn_kernel<4>, dim3((max_np + 127) / 128, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, cross, scale);
+                      int max_mp, int max_tail, int cross, float scale, hipStream_t s) {
+  // grid.x: query tiles of the main regions + max_tail slots per (head, set) for the tail-query workgroups (attn_role)
+  if (((max_mp + 127) / 128) * 4 * nsets >= 1024)
+    hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   else
-    hipLaunchKernelGGL(attn_ks_kernel, dim3((max_np + 63) / 64, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, cross, scale);
+    hipLaunchKernelGGL(attn_ks_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -528,6 +701,22 @@ __global__ void matchability_kernel(const float* x, const float* w, float b, flo
 }
 void launch_matchability(const float* x, const float* w, float b, float* logsig, int T, int ld, hipStream_t s) {
   hipLaunchKernelGGL(matchability_kernel, dim3((T + 63) / 64), dim3(64), 0, s, x, w, b, logsig, T, ld);
+}
+
+// The assignment stage works on a dense copy of the projected descriptors and matchability terms: set s occupies
+// [dense_off, dense_off + n) (padded to 32), gathered from its main region and its tail tokens.
+__global__ __launch_bounds__(64) void lg_densify_kernel(const float* md, const float* logsig, const LgSet* sets, float* md_dense,
+                                                        float* logsig_dense, int ld) {
+  const LgSet st = sets[blockIdx.z];
+  const int i = blockIdx.x * 64 + threadIdx.x, f = blockIdx.y;
+  if (i >= st.n) return;
+  const int tok = i < st.nmain ? st.tok_off + i : st.tail_off + (i - st.nmain);
+  if (f < 256) md_dense[(size_t)f * ld + st.dense_off + i] = md[(size_t)f * ld + tok];
+  else logsig_dense[st.dense_off + i] = logsig[tok];
+}
+void launch_lg_densify(const float* md, const float* logsig, const LgSet* sets, int nsets, int max_n, float* md_dense,
+                       float* logsig_dense, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(lg_densify_kernel, dim3((max_n + 63) / 64, 257, nsets), dim3(64), 0, s, md, logsig, sets, md_dense, logsig_dense, ld);
 }
 
 // sim[pair][i][j] = sum_d md[d][off0+i] * md[d][off1+j]; tile 64 (i) x 128 (j): wave w -> j block pair? 4 waves = 2x2 of 32x64
@@ -552,12 +741,12 @@ __global__ __launch_bounds__(256, 2) void sim_kernel(const float* md, int ld, co
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int e = tid + 256 * u, kk = e >> 4, c4 = e & 15;
-      reinterpret_cast<f32x4*>(sA)[e] = *reinterpret_cast<const f32x4*>(md + (size_t)(k0 + kk) * ld + s0.tok_off + i0 + 4 * c4);
+      reinterpret_cast<f32x4*>(sA)[e] = *reinterpret_cast<const f32x4*>(md + (size_t)(k0 + kk) * ld + s0.dense_off + i0 + 4 * c4);
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int e = tid + 256 * u, kk = e >> 5, c4 = e & 31;
-      reinterpret_cast<f32x4*>(sB)[e] = *reinterpret_cast<const f32x4*>(md + (size_t)(k0 + kk) * ld + s1.tok_off + j0 + 4 * c4);
+      reinterpret_cast<f32x4*>(sB)[e] = *reinterpret_cast<const f32x4*>(md + (size_t)(k0 + kk) * ld + s1.dense_off + j0 + 4 * c4);
     }
     __syncthreads();
 #pragma unroll
@@ -586,17 +775,6 @@ void launch_sim(const float* md, int ld, const LgSet* sets, int npairs, int max_
                      sim, sim_ld, sim_pair_stride);
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-  return v;
-}
-__device__ __forceinline__ float wave_sumf(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
 // row statistics: lse_row[i] = max_j + log sum_j exp(sim - max) over valid j.  One wave per row.
 __global__ __launch_bounds__(64) void row_lse_kernel(const float* sim, int sim_ld, size_t pstride, const LgSet* sets,
                                                      float* lse_row, int ld) {
@@ -610,7 +788,7 @@ __global__ __launch_bounds__(64) void row_lse_kernel(const float* sim, int sim_l
   float sm = 0.0f;
   for (int jj = threadIdx.x; jj < s1.n; jj += 64) sm += __expf(row[jj] - mx);
   sm = wave_sumf(sm);
-  if (threadIdx.x == 0) lse_row[s0.tok_off + i] = mx + __logf(sm);
+  if (threadIdx.x == 0) lse_row[s0.dense_off + i] = mx + __logf(sm);
 }
 
 // column statistics + column argmax of (2*sim - lse_row[i] + ls0[i]): thread per column, 4-way row split per block
@@ -633,7 +811,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* sim, int si
     const float nm = fmaxf(mx, v);
     sm = sm * __expf(mx - nm) + __expf(v - nm);
     mx = nm;
-    const float sc = 2.0f * v - lse_row[s0.tok_off + i] + logsig[s0.tok_off + i];
+    const float sc = 2.0f * v - lse_row[s0.dense_off + i] + logsig[s0.dense_off + i];
     if (sc > bv) { bv = sc; bi = i; }
   }
   rmx[q][lj] = mx; rsm[q][lj] = sm; rbv[q][lj] = bv; rbi[q][lj] = bi;
@@ -643,11 +821,11 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* sim, int si
     for (int k = 1; k < 4; k++) M = fmaxf(M, rmx[k][lj]);
     float S = 0.0f;
     for (int k = 0; k < 4; k++) S += rsm[k][lj] * __expf(rmx[k][lj] - M);
-    lse_col[s1.tok_off + jj] = M + __logf(S);
+    lse_col[s1.dense_off + jj] = M + __logf(S);
     float B = rbv[0][lj]; int I = rbi[0][lj];
     for (int k = 1; k < 4; k++)
       if (rbv[k][lj] > B || (rbv[k][lj] == B && rbi[k][lj] < I)) { B = rbv[k][lj]; I = rbi[k][lj]; }
-    m1[s1.tok_off + jj] = I;
+    m1[s1.dense_off + jj] = I;
   }
 }
 
@@ -659,12 +837,12 @@ __global__ __launch_bounds__(64) void row_argmax_kernel(const float* sim, int si
   const LgSet s0 = sets[2 * pair], s1 = sets[2 * pair + 1];
   if (i >= s0.n) return;
   const float* row = sim + (size_t)pair * pstride + (size_t)i * sim_ld;
-  const float ri = lse_row[s0.tok_off + i], zi = logsig[s0.tok_off + i];
+  const float ri = lse_row[s0.dense_off + i], zi = logsig[s0.dense_off + i];
   float bv = -3e38f;
   int bj = 0x7fffffff;
   for (int jj = threadIdx.x; jj < s1.n; jj += 64) {
     const float v = row[jj];
-    const float sc = (v - ri) + (v - lse_col[s1.tok_off + jj]) + (zi + logsig[s1.tok_off + jj]);
+    const float sc = (v - ri) + (v - lse_col[s1.dense_off + jj]) + (zi + logsig[s1.dense_off + jj]);
     if (sc > bv) { bv = sc; bj = jj; }
   }
 #pragma unroll
@@ -673,7 +851,7 @@ __global__ __launch_bounds__(64) void row_argmax_kernel(const float* sim, int si
     const int oj = __shfl_xor(bj, off);
     if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
   }
-  if (threadIdx.x == 0) { m0[s0.tok_off + i] = bj; max0[s0.tok_off + i] = bv; }
+  if (threadIdx.x == 0) { m0[s0.dense_off + i] = bj; max0[s0.dense_off + i] = bv; }
 }
 
 void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const LgSet* sets, int npairs, int max_n,

@@ -57,7 +57,7 @@ def _check_pair(engine, w, k0, d0, k1, d1, size0=SIZE, size1=SIZE, thr=0.05):
     return m, s, mo, so
 
 
-@pytest.mark.parametrize("n0,n1", [(1024, 1024), (128, 128), (7, 7), (1025, 1000), (33, 700)])
+@pytest.mark.parametrize("n0,n1", [(1024, 1024), (128, 128), (7, 7), (1025, 1000), (33, 700), (1025, 1025), (40, 1030), (64, 70)])
 def test_pair_matches_oracle(engine, lg_weights, n0, n1):
     k0, d0, k1, d1, gt = synth.matching_pair(n0 + n1, n0=n0, n1=n1)
     m, s, mo, so = _check_pair(engine, lg_weights, k0, d0, k1, d1)
