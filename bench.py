@@ -208,7 +208,7 @@ def main():
                        "dynamic_boxes_per_frame": nbox[:4],
                        "concurrent_sequences_per_gpu": NSEQ,
                        "parallelism": f"frame-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "attn_kernel<2> (LightGlue f32 flash attention, 9 self + 9 cross launches)",
+            "roofline": {"bound": "mfma", "kernel": "attn_ks_kernel (LightGlue f32 flash attention, 9 self + 9 cross launches)",
                          "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": attn_launches,

@@ -113,23 +113,41 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
     for (int u = 0; u < NWF; u++) reinterpret_cast<f32x4*>(sW)[tid + 256 * u] = pw[u];
     __syncthreads();
     if (ch + 1 < nchunks) LIN_PREFETCH(ch + 1);
+    // Operand reads run PD k-pair groups ahead of the MFMAs that use them (groups of 2 k-pairs: the compiler merges
+    // their reads into ds_read2st64): left alone, hipcc sinks every read next to its MFMA and waits on it.
+    constexpr int G = 2, NG = KC / 2 / G, PD = 1;   // measured best of G in {1, 2, 4, 8} x PD in {1, 2} (lin_bench)
+    float av[NG][G][NCB], bv[NG][G][NTB];
+    auto rd = [&](int g) {
 #pragma unroll
-    for (int kp = 0; kp < KC / 2; kp++) {
-      float av[NCB], bv[NTB];
+      for (int q = 0; q < G; q++) {
+        const int kp = g * G + q;
 #pragma unroll
-      for (int cb = 0; cb < NCB; cb++) av[cb] = bA[(kp * 2) * LIN_NCO + cb * 32];
+        for (int cb = 0; cb < NCB; cb++) av[g][q][cb] = bA[(kp * 2) * LIN_NCO + cb * 32];
 #pragma unroll
-      for (int tb = 0; tb < NTB; tb++) bv[tb] = bB[(kp * 2) * TT + tb * 32];
-      if constexpr (NCB * NTB == 1) {
-        if (kp & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc2, 0, 0, 0);
-        else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-          for (int tb = 0; tb < NTB; tb++)
-            acc[cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[tb], acc[cb][tb], 0, 0, 0);
+        for (int tb = 0; tb < NTB; tb++) bv[g][q][tb] = bB[(kp * 2) * TT + tb * 32];
       }
+    };
+#pragma unroll
+    for (int g = 0; g < PD; g++) rd(g);
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      if (g + PD < NG) rd(g + PD);
+#pragma unroll
+      for (int q = 0; q < G; q++) {
+        if constexpr (NCB * NTB == 1) {
+          if (q & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][0], bv[g][q][0], acc2, 0, 0, 0);
+          else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][0], bv[g][q][0], acc[0][0], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+            for (int tb = 0; tb < NTB; tb++)
+              acc[cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][cb], bv[g][q][tb], acc[cb][tb], 0, 0, 0);
+        }
+      }
+      // one group of LDS reads (next group's operands), then this group's MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, G * (NCB + NTB), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, G * NCB * NTB, 0);
     }
   }
 #undef LIN_PREFETCH
