@@ -125,6 +125,7 @@ def main():
 
     import threading
     NSEQ = max(1, args.sequences)
+    PROF_EVERY = 4
 
     def step(seq=0):
         if args.host_inputs:
@@ -135,17 +136,24 @@ def main():
     def run_steps(total, collect):
         """`total` steps dealt round-robin to NSEQ concurrent sequences (one host thread each)."""
         outs = [None] * NSEQ
-        acc = [(np.zeros(12), np.zeros(4), np.zeros(3)) for _ in range(NSEQ)]
+        acc = [(np.zeros(12), np.zeros(4), np.zeros(3), np.zeros(3)) for _ in range(NSEQ)]
         errs = []
+        nsamp = [0] * NSEQ
 
         def worker(seq):
             try:
-                for _ in range(total // NSEQ + (1 if seq < total % NSEQ else 0)):
-                    outs[seq] = step(seq)
+                for it in range(total // NSEQ + (1 if seq < total % NSEQ else 0)):
+                    # per-kernel HIP-event timing costs ~0.4 ms per step (166 events): sample every PROF_EVERY-th step
+                    sample = collect and it % PROF_EVERY == 0
                     if collect:
+                        eng.set_profiling(sample)
+                    outs[seq] = step(seq)
+                    if sample:
+                        nsamp[seq] += 1
                         acc[seq][0][:] += eng.layer_timings()
                         acc[seq][1][:] += eng.frontend_timings()
                         acc[seq][2][:] += np.array(eng.lg_attention_profile(), np.float64)
+                        acc[seq][3][:] += np.array(eng.lg_linear_profile(), np.float64)
             except Exception as ex:   # surface worker failures in the main thread
                 errs.append(ex)
         th = [threading.Thread(target=worker, args=(q,)) for q in range(NSEQ)]
@@ -153,7 +161,8 @@ def main():
         for t_ in th: t_.join()
         if errs:
             raise errs[0]
-        return outs, sum(a[0] for a in acc), sum(a[1] for a in acc), sum(a[2] for a in acc)
+        ns = max(sum(nsamp), 1)   # per-step averages over the sampled steps
+        return outs, sum(a[0] for a in acc) / ns, sum(a[1] for a in acc) / ns, sum(a[2] for a in acc) / ns, sum(a[3] for a in acc) / ns
 
     def barrier():
         if world > 1:
@@ -162,10 +171,9 @@ def main():
     reduce_dev = dev if backend == "nccl" else None
 
     run_steps(max(args.warmup, NSEQ), False)
-    eng.set_profiling(True)
     barrier()
     t0 = time.perf_counter()
-    outs, layer_ms, fe_ms, attn = run_steps(args.steps, True)
+    outs, layer_ms, fe_ms, attn, lin = run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     eng.set_profiling(False)
@@ -177,14 +185,15 @@ def main():
     if rank == 0:
         total_frames = B * world * args.steps
         fps = total_frames / dt_max
-        layer_ms /= args.steps
-        fe_ms /= args.steps
         conv_dom_ms = float(sum(layer_ms[i] for i in DOMINANT_LAYERS))
         conv_dom_flops = sum(exact_layer_flops(i, B) for i in DOMINANT_LAYERS)
         conv_achieved = conv_dom_flops / (conv_dom_ms * 1e-3) / 1e12 if conv_dom_ms > 0 else 0.0
-        # dominant kernel of the full front-end by total time: LightGlue attention (18 launches per step)
-        attn_ms, attn_flop, attn_launches = float(attn[0]) / args.steps, float(attn[1]) / args.steps, int(round(attn[2] / args.steps))
-        achieved = attn_flop / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+        # second kernel by total time: LightGlue attention (18 launches per step)
+        attn_ms, attn_flop, attn_launches = float(attn[0]), float(attn[1]), int(round(attn[2]))
+        attn_achieved = attn_flop / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+        # dominant kernel of the full front-end by total time (profiles/: linear_fm_kernel<64>, 55 launches per step)
+        lin_ms, lin_flop, lin_launches = float(lin[0]), float(lin[1]), int(round(lin[2]))
+        achieved = lin_flop / (lin_ms * 1e-3) / 1e12 if lin_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (committed)
         if os.path.exists(tpath):
@@ -208,16 +217,21 @@ def main():
                        "dynamic_boxes_per_frame": nbox[:4],
                        "concurrent_sequences_per_gpu": NSEQ,
                        "parallelism": f"frame-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "attn_ks_kernel (LightGlue f32 flash attention, 9 self + 9 cross launches)",
+            "roofline": {"bound": "mfma", "kernel": "linear_fm_kernel<64> (LightGlue feature-major linear layers: 6 per layer x 9 + final_proj)",
                          "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "launches_per_step": attn_launches,
-                         "avg_launch_ms": round(attn_ms / max(attn_launches, 1), 4),
-                         "algorithmic_gflop_per_step": round(attn_flop / 1e9, 2),
-                         "other_kernels": {DOMINANT_KERNEL: {"achieved": round(conv_achieved, 3),
-                                                             "frac": round(conv_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-                                                             "avg_launch_ms": round(conv_dom_ms / len(DOMINANT_LAYERS), 4),
-                                                             "launches_per_step": len(DOMINANT_LAYERS)}}},
+                         "launches_per_step": lin_launches,
+                         "avg_launch_ms": round(lin_ms / max(lin_launches, 1), 4),
+                         "algorithmic_gflop_per_step": round(lin_flop / 1e9, 2),
+                         "other_kernels": {
+                             "attn_ks_kernel (LightGlue f32 flash attention, 9 self + 9 cross launches)": {
+                                 "achieved": round(attn_achieved, 3), "frac": round(attn_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                 "avg_launch_ms": round(attn_ms / max(attn_launches, 1), 4), "launches_per_step": attn_launches,
+                                 "algorithmic_gflop_per_step": round(attn_flop / 1e9, 2)},
+                             DOMINANT_KERNEL: {"achieved": round(conv_achieved, 3),
+                                               "frac": round(conv_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                               "avg_launch_ms": round(conv_dom_ms / len(DOMINANT_LAYERS), 4),
+                                               "launches_per_step": len(DOMINANT_LAYERS)}}},
             "stages_ms_per_step": {"yolo": round(float(fe_ms[0]), 3), "superpoint": round(float(fe_ms[1]), 3),
                                    "lightglue": round(float(fe_ms[2]), 3), "total": round(float(fe_ms[3]), 3),
                                    "sp_conv_stack_device": round(conv_ms, 3)},

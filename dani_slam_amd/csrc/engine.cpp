@@ -807,6 +807,7 @@ struct LgWeights {
   float match_b = 0.0f;
 };
 
+constexpr int LG_LINEARS = 6 * LG_LAYERS + 1;   // per layer: Wqkv, ffn.0, ffn.3 (self) + qk|v, ffn.0, ffn.3 (cross); final_proj
 struct LgContext {
   int pairs = 0, kmax = 0, ld = 0, sim_ld = 0;
   float *kpts = nullptr, *desc_tm = nullptr;  // token-major staging [ld][2], [ld][256]
@@ -825,9 +826,10 @@ struct LgContext {
   std::vector<LgSet> last_sets;
   // profiling of the attention kernel (dominant kernel of the full front-end): events around its 18 launches
   hipEvent_t aev[36] = {};
+  hipEvent_t lnev[2 * LG_LINEARS] = {};   // around every linear_fm launch of a forward pass
   bool aev_ready = false;
-  float attn_ms = 0.0f;
-  double attn_flops = 0.0;
+  float attn_ms = 0.0f, lin_ms = 0.0f;
+  double attn_flops = 0.0, lin_flops = 0.0;
 };
 
 std::map<Context*, LgContext*> g_lg_ctx;  // guarded by engine mutex
@@ -850,7 +852,7 @@ void lg_release(dani_engine* e) {
     LgContext* L = it->second;
     for (void* p : L->dev_allocs) (void)hipFree(p);
     for (void* p : L->host_allocs) (void)hipHostFree(p);
-    if (L->aev_ready) for (auto& ev : L->aev) (void)hipEventDestroy(ev);
+    if (L->aev_ready) { for (auto& ev : L->aev) (void)hipEventDestroy(ev); for (auto& ev : L->lnev) (void)hipEventDestroy(ev); }
     delete L;
     g_lg_ctx.erase(it);
   }
@@ -1029,8 +1031,12 @@ struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T; };   // T = al
 
 void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof) {
   const int ld = L->ld, nsets = sh.nsets, max_n = sh.max_n, T = sh.T, max_np = round_up(max_n, 32);
-  if (prof && !L->aev_ready) { for (auto& ev : L->aev) (void)hipEventCreate(&ev); L->aev_ready = true; }
-  int ai = 0;
+  if (prof && !L->aev_ready) {
+    for (auto& ev : L->aev) (void)hipEventCreate(&ev);
+    for (auto& ev : L->lnev) (void)hipEventCreate(&ev);
+    L->aev_ready = true;
+  }
+  int ai = 0, li = 0;
   auto attn = [&](const float* Q, const float* K, const float* V, int cross, float scale) {
     if (prof) (void)hipEventRecord(L->aev[ai++], s);
     launch_attention(Q, K, V, L->ctx, ld, L->d_sets, nsets, sh.max_mp, sh.max_tail, cross, scale, s);
@@ -1039,7 +1045,9 @@ void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
   launch_desc_to_fm(L->d_sets, nsets, sh.max_span, L->x, ld, s);
   launch_posenc(L->d_sets, nsets, sh.max_span, W->wr, L->cosb, L->sinb, ld, s);
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
+    if (prof) (void)hipEventRecord(L->lnev[li++], s);
     launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
+    if (prof) (void)hipEventRecord(L->lnev[li++], s);
   };
   for (int i = 0; i < LG_LAYERS; i++) {
     const LgBlockW& S = W->self_[i]; const LgBlockW& C = W->cross_[i];
@@ -1185,6 +1193,12 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
     double fl = 0.0;   // algorithmic: per launch, per set: 4 heads x (QK^T + PV) = 2 * 2 * nq * nk * 256 flop
     for (const LgSet& st : L->last_sets) fl += 9.0 * 4.0 * 256.0 * st.n * ((double)st.n + (double)st.partner_n);
     L->attn_flops = fl;
+    tot = 0.0f;
+    for (int i = 0; i < 2 * LG_LINEARS; i += 2) { float m = 0.0f; (void)hipEventElapsedTime(&m, L->lnev[i], L->lnev[i + 1]); tot += m; }
+    L->lin_ms = tot;
+    double ntok = 0.0;   // algorithmic: valid tokens only; per token 2 * out * in flop per layer
+    for (const LgSet& st : L->last_sets) ntok += st.n;
+    L->lin_flops = ntok * 2.0 * (LG_LAYERS * (768.0 * 256 + 512.0 * 256 + 2 * (512.0 * 512 + 256.0 * 512)) + 256.0 * 256);
   }
   // mutual check + thresholds (filter_matches of the model at 0.1, then LightGlue::filterMatches, src/LightGlue.cpp:98-122)
   int status = DANI_OK;
@@ -1224,6 +1238,15 @@ int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flo
   if (total_ms) *total_ms = L->attn_ms;
   if (total_flop) *total_flop = L->attn_flops;
   if (launches) *launches = 18;
+  return DANI_OK;
+}
+
+int dani_lg_linear_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches) {
+  LgContext* L = last_lg(e);
+  if (!e || !L) return DANI_ERR_INVALID;
+  if (total_ms) *total_ms = L->lin_ms;
+  if (total_flop) *total_flop = L->lin_flops;
+  if (launches) *launches = LG_LINEARS;
   return DANI_OK;
 }
 

@@ -68,7 +68,14 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   float* sX = lds;
   float* sW = lds + KC * TT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-  const int tok0 = (gridDim.x - 1 - blockIdx.x) * TT, ot = blockIdx.y;
+  // 1-D grid, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All output
+  // tiles of one token tile go to the same XCD, back to back, so that the X tile they share is fetched into one L2
+  // once instead of into all eight.
+  const int otiles = (a.OUT + LIN_NCO - 1) / LIN_NCO, ntiles = (a.T + TT - 1) / TT;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tile = (slot / otiles) * 8 + xcd, ot = slot % otiles;
+  if (tile >= ntiles) return;
+  const int tok0 = tile * TT;
   const int K = a.K0 + a.K1, nchunks = K / KC;
   const float* wt = a.w + (size_t)ot * K * LIN_NCO;
   const int wtok = (TT >= 128) ? wave * (TT / 4) : (wave & 1) * 32;   // wave's first token inside the tile
@@ -200,9 +207,10 @@ void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   // (tools/probes/lin_bench.hip, 16 x 1025 keypoints) the 64-token tile -- 86 VGPRs, 32 KB LDS, 5 workgroups per CU --
   // beats the 128-token one (121 VGPRs, 48 KB, 3 per CU) by 9-15 % until the grid is several rounds deep.
   auto wgs = [&](int tt) { return ((T + tt - 1) / tt) * otiles; };
-  if (g_lin_force_tt == 256 || (!g_lin_force_tt && wgs(256) >= 4096)) hipLaunchKernelGGL(linear_fm_kernel<256>, dim3((T + 255) / 256, otiles), dim3(256), 0, s, a);
-  else if (g_lin_force_tt == 128 || (!g_lin_force_tt && wgs(128) >= 4096)) hipLaunchKernelGGL(linear_fm_kernel<128>, dim3((T + 127) / 128, otiles), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(linear_fm_kernel<64>, dim3((T + 63) / 64, otiles), dim3(256), 0, s, a);
+  auto grid = [&](int tt) { return dim3((unsigned)(((T + tt - 1) / tt + 7) / 8 * 8 * otiles)); };   // see the kernel: 8 XCDs
+  if (g_lin_force_tt == 256 || (!g_lin_force_tt && wgs(256) >= 4096)) hipLaunchKernelGGL(linear_fm_kernel<256>, grid(256), dim3(256), 0, s, a);
+  else if (g_lin_force_tt == 128 || (!g_lin_force_tt && wgs(128) >= 4096)) hipLaunchKernelGGL(linear_fm_kernel<128>, grid(128), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(linear_fm_kernel<64>, grid(64), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------------

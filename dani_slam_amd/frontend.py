@@ -85,6 +85,7 @@ def load_library():
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_lg_attention_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
+    lib.dani_lg_linear_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
     lib.dani_lg_debug_fetch.argtypes = [C.c_void_p, C.c_int32, _f, _i32, _f, C.c_int32]
     lib.dani_yolo_detect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_float, C.c_float, _f, C.c_int32, _i32]
@@ -294,6 +295,12 @@ class Engine:
         """(total ms, total algorithmic flop, launches) of the attention kernel in the last LightGlue call (profiling on)."""
         ms = C.c_float(0); fl = C.c_double(0); n = C.c_int32(0)
         self._check(self.lib.dani_lg_attention_profile(self.h, C.byref(ms), C.byref(fl), C.byref(n)))
+        return ms.value, fl.value, n.value
+
+    def lg_linear_profile(self):
+        """(total ms, total algorithmic flop, launches) of the linear_fm launches in the last LightGlue call (profiling on)."""
+        ms = C.c_float(0); fl = C.c_double(0); n = C.c_int32(0)
+        self._check(self.lib.dani_lg_linear_profile(self.h, C.byref(ms), C.byref(fl), C.byref(n)))
         return ms.value, fl.value, n.value
 
     def lg_debug_fetch(self, set_index, n):

@@ -160,6 +160,8 @@ DANI_API int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int3
 /* With dani_set_profiling(e, 1): summed duration (HIP events on the engine's stream) and algorithmic FLOP of the 18
  * attention-kernel launches of the last LightGlue call on this thread (bench.py roofline of the dominant kernel). */
 DANI_API int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches);
+/* same for the feature-major linear layers of the forward pass (55 launches: 6 per layer + final_proj) */
+DANI_API int dani_lg_linear_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches);
 
 /* Test hook: final descriptors (after the 9 layers) of keypoint set `set` (2*pair + side) of the last LightGlue
  * call on this thread, as [n][256] f32, and the raw row results (best column and log-score per query row). */
