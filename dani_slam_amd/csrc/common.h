@@ -159,11 +159,11 @@ void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const
 // ---- YOLO kernels (yolo_kernels.hip) ---------------------------------------------------------------
 void launch_yolo_preproc(const uint8_t* bgr, int B, int sw, int sh, int sstride, size_t sframe, const ActDesc& out,
                          hipStream_t s);
-void launch_maxpool5(const float* in, float* out, int C, int H, int W, int Hp, int Wp, size_t fs, int B, hipStream_t s);
+void launch_sppf_pool(float* cat, int C, int H, int W, int Hp, int Wp, size_t fs, int B, hipStream_t s);
 void launch_upsample2(const float* src, int sHp, int sWp, size_t sfs, float* dst, int C, int Hd, int Wd, int dHp, int dWp,
                       size_t dfs, int B, hipStream_t s);
-void launch_yolo_decode(const float* raw, int ny, int nx, int Hp, int Wp, size_t fs, int level, int level_base,
-                        float score_thresh, float* cand, int* cand_count, int cand_cap, int B, hipStream_t s);
+void launch_yolo_decode(const ActDesc* raws[3], float score_thresh, float* cand, int* cand_count, int cand_cap, int B,
+                        hipStream_t s);
 // host: greedy class-agnostic NMS of the reference (src/YoloDetect.cpp:95-144) on candidate records of 8 floats
 int yolo_nms_host(const float* cand8, int n, float iou_thresh, float* dets6, int cap);
 // host: Detect()'s box bookkeeping + RefineDynamicBoxes (src/YoloDetect.cpp:51-80, 148-208)

@@ -1022,6 +1022,7 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
   if ((rc = lg_host(e, L, (void**)&L->h_stage, (size_t)ld * 258 * 4))) return rc;
   if ((rc = lg_host(e, L, (void**)&L->h_m0, (size_t)ld * 12))) return rc;
   L->h_m1 = L->h_m0 + ld; L->h_max0 = reinterpret_cast<float*>(L->h_m0 + 2 * (size_t)ld);
+  HIP_TRY(e, hipDeviceSynchronize());   // null-stream zero fills vs the engine's non-blocking streams
   L->pairs = pairs; L->kmax = kmax; L->ld = ld;
   return 0;
 }
@@ -1332,7 +1333,8 @@ void yolo_shape(ActDesc& a, int C, int H, int W, int pady) {
 struct YLayer { const char* name; int cin, cout, k, s; int scale; bool act; };  // scale = output pyramid level 0..4
 
 // output dims of the five pyramid levels for the fixed 380x640 network input
-const int kYH[5] = {190, 95, 48, 24, 12}, kYW[5] = {320, 160, 80, 40, 20};
+constexpr int kYH[5] = {190, 95, 48, 24, 12}, kYW[5] = {320, 160, 80, 40, 20};
+static_assert(kYH[4] * kYW[4] <= 1024, "sppf_pool_kernel keeps one stride-32 plane in LDS");
 
 ConvVariant yolo_variant(int k, int s, int scale, bool act) {
   const bool row32 = scale <= 1;   // 190x320 and 95x160 use 8x32 tiles, the rest 16x16
@@ -1343,13 +1345,30 @@ ConvVariant yolo_variant(int k, int s, int scale, bool act) {
   return row32 ? CONV1_ROW32_SILU : CONV1_BLK16_SILU;
 }
 
-int yolo_pack(dani_engine* e, YoloWeights* W, const std::string& name, int cin, int cout, int k, int s, int scale, bool act,
-              bool detect) {
-  const std::string wn = detect ? name + ".weight" : name + ".weight", bn = name + ".bias";
+int yolo_get(dani_engine* e, const std::string& name, int cin, int cout, int k, const std::vector<float>** w, const std::vector<float>** b) {
+  const std::string wn = name + ".weight", bn = name + ".bias";
   auto wi = e->tensors.find(wn), bi = e->tensors.find(bn);
   if (wi == e->tensors.end() || bi == e->tensors.end()) return fail(e, DANI_ERR_WEIGHTS, "missing tensor %s / %s", wn.c_str(), bn.c_str());
   if (wi->second.size() != (size_t)cout * cin * k * k || bi->second.size() != (size_t)cout)
     return fail(e, DANI_ERR_WEIGHTS, "tensor %s has %zu floats, expected [%d,%d,%d,%d]", wn.c_str(), wi->second.size(), cout, cin, k, k);
+  *w = &wi->second; *b = &bi->second;
+  return 0;
+}
+
+int yolo_pack_raw(dani_engine* e, YoloWeights* W, const std::string& name, const std::vector<float>& wsrc, const std::vector<float>& bsrc,
+                  int cin, int cout, int k, int s, int scale, bool act);
+
+int yolo_pack(dani_engine* e, YoloWeights* W, const std::string& name, int cin, int cout, int k, int s, int scale, bool act,
+              bool detect) {
+  (void)detect;
+  const std::vector<float>* w = nullptr; const std::vector<float>* b = nullptr;
+  int rc = yolo_get(e, name, cin, cout, k, &w, &b);
+  if (rc) return rc;
+  return yolo_pack_raw(e, W, name, *w, *b, cin, cout, k, s, scale, act);
+}
+
+int yolo_pack_raw(dani_engine* e, YoloWeights* W, const std::string& name, const std::vector<float>& wsrc, const std::vector<float>& bsrc,
+                  int cin, int cout, int k, int s, int scale, bool act) {
   YConv& yc = W->convs[name];
   ConvLayerPlan& L = yc.plan;
   L.variant = yolo_variant(k, s, scale, act);
@@ -1368,7 +1387,7 @@ int yolo_pack(dani_engine* e, YoloWeights* W, const std::string& name, int cin, 
   const int nco = conv_variant_nco(L.variant);
   L.cout_tiles = (cout + nco - 1) / nco;
   std::vector<float> wp((size_t)L.cout_tiles * nco * L.CinPad * k * k), bp((size_t)L.cout_tiles * nco);
-  pack_conv_weights(wi->second.data(), bi->second.data(), cin, cout, k, L.CC, nco, wp.data(), bp.data());
+  pack_conv_weights(wsrc.data(), bsrc.data(), cin, cout, k, L.CC, nco, wp.data(), bp.data());
   HIP_TRY(e, hipMalloc((void**)&L.w_packed, wp.size() * 4)); e->weight_allocs.push_back(L.w_packed);
   HIP_TRY(e, hipMalloc((void**)&L.bias_packed, bp.size() * 4)); e->weight_allocs.push_back(L.bias_packed);
   HIP_TRY(e, hipMemcpy(L.w_packed, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
@@ -1396,7 +1415,15 @@ int yolo_finalize(dani_engine* e) {
   for (const C3Def& c : kC3) {
     const std::string p = c.name;
     const int c_ = c.c2 / 2;
-    YP(p + ".cv1.conv", c.c1, c_, 1, 1, c.scale) YP(p + ".cv2.conv", c.c1, c_, 1, 1, c.scale) YP(p + ".cv3.conv", 2 * c_, c.c2, 1, 1, c.scale)
+    {   // cv1 and cv2 read the same input and write adjacent channel slices of the concat buffer: one 2c_-row conv
+      const std::vector<float>*w1, *b1, *w2, *b2;
+      if ((rc = yolo_get(e, p + ".cv1.conv", c.c1, c_, 1, &w1, &b1))) return rc;
+      if ((rc = yolo_get(e, p + ".cv2.conv", c.c1, c_, 1, &w2, &b2))) return rc;
+      std::vector<float> w12(*w1), b12(*b1);
+      w12.insert(w12.end(), w2->begin(), w2->end()); b12.insert(b12.end(), b2->begin(), b2->end());
+      if ((rc = yolo_pack_raw(e, W, p + ".cv12", w12, b12, c.c1, 2 * c_, 1, 1, c.scale, true))) return rc;
+    }
+    YP(p + ".cv3.conv", 2 * c_, c.c2, 1, 1, c.scale)
     for (int j = 0; j < c.n; j++) {
       YP(p + ".m." + std::to_string(j) + ".cv1.conv", c_, c_, 1, 1, c.scale)
       YP(p + ".m." + std::to_string(j) + ".cv2.conv", c_, c_, 3, 1, c.scale)
@@ -1456,6 +1483,8 @@ int yolo_ensure(dani_engine* e, Context* c, YoloContext** out, int B, size_t img
   HIP_TRY(e, hipHostMalloc((void**)&Y->h_count, (size_t)B * 4, hipHostMallocDefault)); Y->host_allocs.push_back(Y->h_count);
   Y->d_img_bytes = std::max(img_bytes, Y->d_img_bytes);
   HIP_TRY(e, hipMalloc((void**)&Y->d_img, Y->d_img_bytes)); Y->dev_allocs.push_back(Y->d_img);
+  // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
+  HIP_TRY(e, hipDeviceSynchronize());
   Y->B = B;
   return 0;
 }
@@ -1482,8 +1511,8 @@ void yolo_c3(const YoloWeights* W, YoloContext* Y, const C3Def& c3, YView x, YVi
                         std::string(c3.name) == "model.6" || std::string(c3.name) == "model.8";   // backbone C3s
   const ActDesc& cat = Y->buf.at(p + ".cat"); const ActDesc& tmp = Y->buf.at(p + ".tmp");
   YView y{&cat, 0, c_}, y2{&cat, c_, c_}, t{&tmp, 0, c_};
-  yolo_conv(W, p + ".cv1.conv", x, y, nullptr, B, s);
-  yolo_conv(W, p + ".cv2.conv", x, y2, nullptr, B, s);
+  (void)y2;
+  yolo_conv(W, p + ".cv12", x, YView{&cat, 0, 2 * c_}, nullptr, B, s);   // [cv1(x) | cv2(x)] in one launch
   for (int j = 0; j < c3.n; j++) {
     yolo_conv(W, p + ".m." + std::to_string(j) + ".cv1.conv", y, t, nullptr, B, s);
     yolo_conv(W, p + ".m." + std::to_string(j) + ".cv2.conv", t, y, shortcut ? &y : nullptr, B, s);   // y = y + cv2(cv1(y)) in place
@@ -1495,6 +1524,7 @@ void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thres
   auto& b = Y->buf;
   auto V = [&](const char* n) { const ActDesc& a = b.at(n); return YView{&a, 0, a.C}; };
   auto S = [&](const char* n, int c0, int C) { return YView{&b.at(n), c0, C}; };
+  (void)hipMemsetAsync(Y->cand_count, 0, (size_t)B * 4, s);   // candidate counters of the decode at the end
   yolo_conv(W, "model.0.conv", YView{&b.at("in"), 0, 4}, V("b0"), nullptr, B, s);
   yolo_conv(W, "model.1.conv", V("b0"), V("b1"), nullptr, B, s);
   yolo_c3(W, Y, kC3[0], V("b1"), V("b2"), B, s);
@@ -1508,10 +1538,7 @@ void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thres
   yolo_conv(W, "model.9.cv1.conv", V("b8"), S("cat9", 0, 256), nullptr, B, s);
   {
     const ActDesc& c9 = b.at("cat9");
-    const size_t plane = (size_t)c9.Hp * c9.Wp;
-    for (int i = 0; i < 3; i++)
-      launch_maxpool5(c9.p + (size_t)(256 * i) * plane, c9.p + (size_t)(256 * (i + 1)) * plane, 256, c9.H, c9.W, c9.Hp, c9.Wp,
-                      c9.frame_stride(), B, s);
+    launch_sppf_pool(c9.p, 256, c9.H, c9.W, c9.Hp, c9.Wp, c9.frame_stride(), B, s);
   }
   yolo_conv(W, "model.9.cv2.conv", V("cat9"), V("b9"), nullptr, B, s);
   yolo_conv(W, "model.10.conv", V("b9"), S("cat22", 256, 256), nullptr, B, s);   // x10 -> second half of cat22
@@ -1532,14 +1559,8 @@ void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thres
   yolo_conv(W, "model.24.m.0", V("b17"), V("raw0"), nullptr, B, s);
   yolo_conv(W, "model.24.m.1", V("b20"), V("raw1"), nullptr, B, s);
   yolo_conv(W, "model.24.m.2", V("b23"), V("raw2"), nullptr, B, s);
-  (void)hipMemsetAsync(Y->cand_count, 0, (size_t)B * 4, s);
-  int base = 0;
-  const char* raws[3] = {"raw0", "raw1", "raw2"};
-  for (int i = 0; i < 3; i++) {
-    const ActDesc& r = b.at(raws[i]);
-    launch_yolo_decode(r.p, r.H, r.W, r.Hp, r.Wp, r.frame_stride(), i, base, score_thresh, Y->cand, Y->cand_count, YOLO_CAND_CAP, B, s);
-    base += 3 * r.H * r.W;
-  }
+  const ActDesc* raws[3] = {&b.at("raw0"), &b.at("raw1"), &b.at("raw2")};
+  launch_yolo_decode(raws, score_thresh, Y->cand, Y->cand_count, YOLO_CAND_CAP, B, s);
 }
 
 thread_local YoloContext* t_last_yolo = nullptr;

@@ -54,57 +54,76 @@ void launch_yolo_preproc(const uint8_t* bgr, int B, int sw, int sh, int sstride,
                      out.Wp, out.pady);
 }
 
-// nn.MaxPool2d(5, 1, 2) on C planes (SPPF); in/out are channel slices of the same concat buffer
-__global__ __launch_bounds__(64) void maxpool5_kernel(const float* in, float* out, int H, int W, int Hp, int Wp,
-                                                      size_t fs) {
-  const int x = threadIdx.x, y = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
-  if (x >= W) return;
-  const float* p = in + (size_t)b * fs + (size_t)c * Hp * Wp;
-  float m = -INFINITY;
-  for (int dy = -2; dy <= 2; dy++) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= H) continue;
-    for (int dx = -2; dx <= 2; dx++) {
-      const int xx = x + dx;
-      if (xx >= 0 && xx < W) m = fmaxf(m, p[(size_t)(yy + PADY) * Wp + xx + PADX]);
+// SPPF: the three chained nn.MaxPool2d(5, 1, 2) of one channel plane in one workgroup (plane in LDS, -inf padding as
+// in PyTorch): out1 = mp5(in), out2 = mp5(out1), out3 = mp5(out2), written to the three following 256-channel slices
+// of the concat buffer.  One launch instead of three 24576-workgroup ones.
+__global__ __launch_bounds__(256) void sppf_pool_kernel(float* cat, int C, int H, int W, int Hp, int Wp, size_t fs) {
+  __shared__ float pl[2][1024];
+  const int c = blockIdx.x, b = blockIdx.y, n = H * W;
+  const size_t plane = (size_t)Hp * Wp;
+  float* base = cat + (size_t)b * fs + (size_t)c * plane;
+  for (int i = threadIdx.x; i < n; i += 256) pl[0][i] = base[(size_t)(i / W + PADY) * Wp + i % W + PADX];
+  __syncthreads();
+  for (int k = 1; k <= 3; k++) {
+    const float* src = pl[(k - 1) & 1];
+    float* dst = pl[k & 1];
+    float* out = base + (size_t)(k * C) * plane;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int y = i / W, x = i % W;
+      float m = -INFINITY;
+      for (int yy = max(y - 2, 0); yy <= min(y + 2, H - 1); yy++)
+        for (int xx = max(x - 2, 0); xx <= min(x + 2, W - 1); xx++) m = fmaxf(m, src[yy * W + xx]);
+      dst[i] = m;
+      out[(size_t)(y + PADY) * Wp + x + PADX] = m;
     }
+    __syncthreads();
   }
-  out[(size_t)b * fs + (size_t)c * Hp * Wp + (size_t)(y + PADY) * Wp + x + PADX] = m;
 }
 
-void launch_maxpool5(const float* in, float* out, int C, int H, int W, int Hp, int Wp, size_t fs, int B, hipStream_t s) {
-  hipLaunchKernelGGL(maxpool5_kernel, dim3(H, C, B), dim3(64), 0, s, in, out, H, W, Hp, Wp, fs);
+void launch_sppf_pool(float* cat, int C, int H, int W, int Hp, int Wp, size_t fs, int B, hipStream_t s) {
+  hipLaunchKernelGGL(sppf_pool_kernel, dim3(C, B), dim3(256), 0, s, cat, C, H, W, Hp, Wp, fs);
 }
 
-// nn.Upsample(scale 2, nearest): src [C][H][W] slice -> dst [C][2H][2W] slice (only Hd x Wd written)
-__global__ __launch_bounds__(64) void upsample2_kernel(const float* src, int sHp, int sWp, size_t sfs, float* dst, int Hd,
-                                                       int Wd, int dHp, int dWp, size_t dfs) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y % Hd, c = blockIdx.y / Hd, b = blockIdx.z;
-  if (x >= Wd) return;
-  dst[(size_t)b * dfs + (size_t)c * dHp * dWp + (size_t)(y + PADY) * dWp + x + PADX] =
-      src[(size_t)b * sfs + (size_t)c * sHp * sWp + (size_t)((y >> 1) + PADY) * sWp + (x >> 1) + PADX];
+// nn.Upsample(scale 2, nearest): src [C][H][W] slice -> dst [C][2H][2W] slice (only Hd x Wd written); one workgroup
+// per (channel, frame) plane
+__global__ __launch_bounds__(256) void upsample2_kernel(const float* src, int sHp, int sWp, size_t sfs, float* dst, int Hd,
+                                                        int Wd, int dHp, int dWp, size_t dfs) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* sp = src + (size_t)b * sfs + (size_t)c * sHp * sWp;
+  float* dp = dst + (size_t)b * dfs + (size_t)c * dHp * dWp;
+  for (int i = threadIdx.x; i < Hd * Wd; i += 256) {
+    const int y = i / Wd, x = i % Wd;
+    dp[(size_t)(y + PADY) * dWp + x + PADX] = sp[(size_t)((y >> 1) + PADY) * sWp + (x >> 1) + PADX];
+  }
 }
 
 void launch_upsample2(const float* src, int sHp, int sWp, size_t sfs, float* dst, int C, int Hd, int Wd, int dHp, int dWp,
                       size_t dfs, int B, hipStream_t s) {
-  hipLaunchKernelGGL(upsample2_kernel, dim3((Wd + 63) / 64, Hd * C, B), dim3(64), 0, s, src, sHp, sWp, sfs, dst, Hd, Wd, dHp,
-                     dWp, dfs);
+  hipLaunchKernelGGL(upsample2_kernel, dim3(C, B), dim3(256), 0, s, src, sHp, sWp, sfs, dst, Hd, Wd, dHp, dWp, dfs);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Detect decode + score filter: one thread per (anchor, cell) of one level.  sigmoid = 1/(1+dani_expf(-x)),
+// Detect decode + score filter: one thread per (anchor, cell), all three levels in one launch.  sigmoid = 1/(1+dani_expf(-x)),
 // xy = (s*2 - 0.5 + grid) * stride, wh = (s*2)^2 * anchor, score = obj * max(cls) > thresh -> candidate record
 // {pred index, cx, cy, w, h, obj, max cls, argmax cls} appended with an atomic counter (the host sorts the few
 // records by pred index, so the result does not depend on the append order).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void yolo_decode_kernel(const float* raw, int ny, int nx, int Hp, int Wp, size_t fs,
-                                                         int level_base, float stride, float aw0, float ah0, float aw1,
-                                                         float ah1, float aw2, float ah2, float score_thresh, float* cand,
-                                                         int* cand_count, int cand_cap) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y % ny, a = blockIdx.y / ny, b = blockIdx.z;
+struct DecodeLevels {
+  const float* raw[3];
+  int ny[3], nx[3], Hp[3], Wp[3], base[3], row0[3];   // row0: first blockIdx.y of the level (rows = anchors x ny)
+  size_t fs[3];
+};
+
+__global__ __launch_bounds__(64) void yolo_decode_kernel(DecodeLevels lv, float score_thresh, float* cand, int* cand_count,
+                                                         int cand_cap) {
+  const int level = blockIdx.y >= lv.row0[2] ? 2 : (blockIdx.y >= lv.row0[1] ? 1 : 0);
+  const int ny = lv.ny[level], nx = lv.nx[level], row = blockIdx.y - lv.row0[level];
+  const int x = blockIdx.x * 64 + threadIdx.x, y = row % ny, a = row / ny, b = blockIdx.z;
   if (x >= nx) return;
-  const size_t plane = (size_t)Hp * Wp;
-  const float* p = raw + (size_t)b * fs + (size_t)(a * 85) * plane + (size_t)(y + PADY) * Wp + x + PADX;
+  const float anchors[3][6] = {{10, 13, 16, 30, 33, 23}, {30, 61, 62, 45, 59, 119}, {116, 90, 156, 198, 373, 326}};
+  const float stride = level == 0 ? 8.0f : (level == 1 ? 16.0f : 32.0f);
+  const size_t plane = (size_t)lv.Hp[level] * lv.Wp[level];
+  const float* p = lv.raw[level] + (size_t)b * lv.fs[level] + (size_t)(a * 85) * plane + (size_t)(y + PADY) * lv.Wp[level] + x + PADX;
   const float obj = 1.0f / (1.0f + dani_expf(-p[4 * plane]));
   float best = -1.0f;
   int bi = 0;
@@ -116,25 +135,30 @@ __global__ __launch_bounds__(64) void yolo_decode_kernel(const float* raw, int n
   if (!(score > score_thresh)) return;
   const float sx = 1.0f / (1.0f + dani_expf(-p[0])), sy = 1.0f / (1.0f + dani_expf(-p[plane]));
   const float sw = 1.0f / (1.0f + dani_expf(-p[2 * plane])), sh = 1.0f / (1.0f + dani_expf(-p[3 * plane]));
-  const float aw = a == 0 ? aw0 : (a == 1 ? aw1 : aw2), ah = a == 0 ? ah0 : (a == 1 ? ah1 : ah2);
+  const float aw = anchors[level][2 * a], ah = anchors[level][2 * a + 1];
   const float cx = (sx * 2.0f - 0.5f + (float)x) * stride, cy = (sy * 2.0f - 0.5f + (float)y) * stride;
   const float w2 = sw * 2.0f, h2 = sh * 2.0f;
   const float bw = (w2 * w2) * aw, bh = (h2 * h2) * ah;
   const int slot = atomicAdd(&cand_count[b], 1);
   if (slot < cand_cap) {
     float* o = cand + ((size_t)b * cand_cap + slot) * 8;
-    o[0] = __int_as_float(level_base + (a * ny + y) * nx + x);
+    o[0] = __int_as_float(lv.base[level] + (a * ny + y) * nx + x);
     o[1] = cx; o[2] = cy; o[3] = bw; o[4] = bh; o[5] = obj; o[6] = best; o[7] = __int_as_float(bi);
   }
 }
 
-void launch_yolo_decode(const float* raw, int ny, int nx, int Hp, int Wp, size_t fs, int level, int level_base,
-                        float score_thresh, float* cand, int* cand_count, int cand_cap, int B, hipStream_t s) {
-  static const float anchors[3][6] = {{10, 13, 16, 30, 33, 23}, {30, 61, 62, 45, 59, 119}, {116, 90, 156, 198, 373, 326}};
-  static const float strides[3] = {8.0f, 16.0f, 32.0f};
-  const float* an = anchors[level];
-  hipLaunchKernelGGL(yolo_decode_kernel, dim3((nx + 63) / 64, ny * 3, B), dim3(64), 0, s, raw, ny, nx, Hp, Wp, fs, level_base,
-                     strides[level], an[0], an[1], an[2], an[3], an[4], an[5], score_thresh, cand, cand_count, cand_cap);
+// all three Detect levels in one launch
+void launch_yolo_decode(const ActDesc* raws[3], float score_thresh, float* cand, int* cand_count, int cand_cap, int B, hipStream_t s) {
+  DecodeLevels lv;
+  int base = 0, row = 0, maxnx = 0;
+  for (int i = 0; i < 3; i++) {
+    const ActDesc& r = *raws[i];
+    lv.raw[i] = r.p; lv.ny[i] = r.H; lv.nx[i] = r.W; lv.Hp[i] = r.Hp; lv.Wp[i] = r.Wp; lv.fs[i] = r.frame_stride();
+    lv.base[i] = base; lv.row0[i] = row;
+    base += 3 * r.H * r.W; row += 3 * r.H;
+    maxnx = r.W > maxnx ? r.W : maxnx;
+  }
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3((maxnx + 63) / 64, row, B), dim3(64), 0, s, lv, score_thresh, cand, cand_count, cand_cap);
 }
 
 }  // namespace dani
