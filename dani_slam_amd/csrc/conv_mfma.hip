@@ -305,33 +305,47 @@ void pack_conv_weights(const float* w, const float* bias, int Cin, int Cout, int
 __global__ __launch_bounds__(256) void conv1a_kernel(const uint8_t* img, int H, int W, int stride, size_t fstride,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      float* out, int oHp, int oWp) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  // one thread = 4 horizontally adjacent pixels: a 3 x 6 input window in registers, one 16-byte store per channel
+  const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int b = blockIdx.z;
   if (x >= W || y >= H) return;
   const uint8_t* im = img + (size_t)b * fstride;
-  float p[9];
+  float p[3][6];
 #pragma unroll
   for (int ky = 0; ky < 3; ky++)
 #pragma unroll
-    for (int kx = 0; kx < 3; kx++) {
-      const int yy = y + ky - 1, xx = x + kx - 1;
-      p[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)im[(size_t)yy * stride + xx] / 255.0f : 0.0f;
+    for (int c = 0; c < 6; c++) {
+      const int yy = y + ky - 1, xx = x + c - 1;
+      p[ky][c] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? (float)im[(size_t)yy * stride + xx] / 255.0f : 0.0f;
     }
   const size_t oplane = (size_t)oHp * oWp;
   float* o = out + (size_t)b * 64 * oplane + (size_t)(y + PADY) * oWp + x + PADX;
-#pragma unroll 4
+  const bool full = x + 3 < W && ((oWp & 3) == 0);   // PADX = 4 and x % 4 == 0: the store is 16-byte aligned
+#pragma unroll 2
   for (int co = 0; co < 64; co++) {
-    float acc = bias[co];
+    const float bv = bias[co];
+    float acc[4] = {bv, bv, bv, bv};
 #pragma unroll
-    for (int t = 0; t < 9; t++) acc = __builtin_fmaf(p[t], w[co * 9 + t], acc);
-    o[(size_t)co * oplane] = acc > 0.0f ? acc : 0.0f;
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        const float wv = w[co * 9 + ky * 3 + kx];
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = __builtin_fmaf(p[ky][kx + q], wv, acc[q]);
+      }
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = acc[q] > 0.0f ? acc[q] : 0.0f;
+    if (full) *reinterpret_cast<f32x4*>(o + (size_t)co * oplane) = v;
+    else
+      for (int q = 0; q < 4 && x + q < W; q++) o[(size_t)co * oplane + q] = v[q];
   }
 }
 
 void launch_conv1a(const uint8_t* img, int B, int H, int W, int stride, size_t fstride, const float* w,
                    const float* bias, const ActDesc& out, hipStream_t s) {
-  dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+  dim3 grid((W + 255) / 256, (H + 3) / 4, B);
   hipLaunchKernelGGL(conv1a_kernel, grid, dim3(256), 0, s, img, H, W, stride, fstride, w, bias, out.p, out.Hp, out.Wp);
 }
 
