@@ -89,7 +89,13 @@ struct Context {
   float layer_ms[12] = {};
   std::vector<void*> dev_allocs, host_allocs;
   bool busy = false;
+  struct LgContext* lg = nullptr;       // LightGlue / YOLO workspaces of this context (created on first use, owned)
+  struct YoloContext* yolo = nullptr;
 };
+
+struct LgWeights;
+struct YoloWeights;
+struct SeqState;
 
 }  // namespace
 
@@ -106,6 +112,9 @@ struct dani_engine {
   std::vector<Context*> ctxs;
   std::mutex mu;
   bool profiling = false;
+  LgWeights* lgw = nullptr;             // packed LightGlue / YOLO weights (owned; device buffers are in weight_allocs)
+  YoloWeights* yw = nullptr;
+  std::map<int, SeqState*> seqs;        // dani_frontend_batch sequences (own context + cached previous frame), under mu
 };
 
 namespace {
@@ -832,32 +841,26 @@ struct LgContext {
   double attn_flops = 0.0, lin_flops = 0.0;
 };
 
-std::map<Context*, LgContext*> g_lg_ctx;  // guarded by engine mutex
-std::map<dani_engine*, LgWeights*> g_lg_w;
 
 LgWeights* lg_weights(dani_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
-  auto it = g_lg_w.find(e);
-  if (it != g_lg_w.end()) return it->second;
-  LgWeights* w = new LgWeights();
-  g_lg_w[e] = w;
-  return w;
+  if (!e->lgw) e->lgw = new LgWeights();
+  return e->lgw;
 }
 
 void lg_release(dani_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
   for (Context* c : e->ctxs) {
-    auto it = g_lg_ctx.find(c);
-    if (it == g_lg_ctx.end()) continue;
-    LgContext* L = it->second;
+    LgContext* L = c->lg;
+    if (!L) continue;
     for (void* p : L->dev_allocs) (void)hipFree(p);
     for (void* p : L->host_allocs) (void)hipHostFree(p);
     if (L->aev_ready) { for (auto& ev : L->aev) (void)hipEventDestroy(ev); for (auto& ev : L->lnev) (void)hipEventDestroy(ev); }
     delete L;
-    g_lg_ctx.erase(it);
+    c->lg = nullptr;
   }
-  auto w = g_lg_w.find(e);
-  if (w != g_lg_w.end()) { delete w->second; g_lg_w.erase(w); }   // device weights are in e->weight_allocs
+  delete e->lgw;   // device weights are in e->weight_allocs
+  e->lgw = nullptr;
 }
 
 int lg_upload(dani_engine* e, const std::vector<float>& v, float** out) {
@@ -997,8 +1000,8 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
   LgContext* L;
   {
     std::lock_guard<std::mutex> lk(e->mu);
-    auto it = g_lg_ctx.find(c);
-    if (it == g_lg_ctx.end()) { L = new LgContext(); g_lg_ctx[c] = L; } else L = it->second;
+    if (!c->lg) c->lg = new LgContext();
+    L = c->lg;
   }
   *out = L;
   if (L->pairs >= pairs && L->kmax >= kmax) return 0;
@@ -1078,7 +1081,7 @@ thread_local LgContext* t_last_lg = nullptr;
 LgContext* last_lg(dani_engine* e) {
   if (!e || !t_last_lg) return nullptr;
   std::lock_guard<std::mutex> lk(e->mu);
-  for (Context* c : e->ctxs) { auto it = g_lg_ctx.find(c); if (it != g_lg_ctx.end() && it->second == t_last_lg) return t_last_lg; }
+  for (Context* c : e->ctxs) if (c->lg && c->lg == t_last_lg) return t_last_lg;
   return nullptr;
 }
 thread_local std::function<void()>* t_overlap_fn = nullptr;   // set by the fused front-end around its LightGlue call
@@ -1288,15 +1291,11 @@ struct YoloWeights {
   bool ready = false;
   std::map<std::string, YConv> convs;   // by public tensor prefix, e.g. "model.2.cv1.conv"
 };
-std::map<dani_engine*, YoloWeights*> g_yolo_w;
 
 YoloWeights* yolo_weights(dani_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
-  auto it = g_yolo_w.find(e);
-  if (it != g_yolo_w.end()) return it->second;
-  YoloWeights* w = new YoloWeights();
-  g_yolo_w[e] = w;
-  return w;
+  if (!e->yw) e->yw = new YoloWeights();
+  return e->yw;
 }
 
 struct YoloContext {
@@ -1307,21 +1306,19 @@ struct YoloContext {
   float* h_cand = nullptr; int* h_count = nullptr;
   std::vector<void*> dev_allocs, host_allocs;
 };
-std::map<Context*, YoloContext*> g_yolo_ctx;
 
 void yolo_release(dani_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
   for (Context* c : e->ctxs) {
-    auto it = g_yolo_ctx.find(c);
-    if (it == g_yolo_ctx.end()) continue;
-    YoloContext* Y = it->second;
+    YoloContext* Y = c->yolo;
+    if (!Y) continue;
     for (void* p : Y->dev_allocs) (void)hipFree(p);
     for (void* p : Y->host_allocs) (void)hipHostFree(p);
     delete Y;
-    g_yolo_ctx.erase(it);
+    c->yolo = nullptr;
   }
-  auto w = g_yolo_w.find(e);
-  if (w != g_yolo_w.end()) { delete w->second; g_yolo_w.erase(w); }
+  delete e->yw;
+  e->yw = nullptr;
 }
 
 void yolo_shape(ActDesc& a, int C, int H, int W, int pady) {
@@ -1441,8 +1438,8 @@ int yolo_ensure(dani_engine* e, Context* c, YoloContext** out, int B, size_t img
   YoloContext* Y;
   {
     std::lock_guard<std::mutex> lk(e->mu);
-    auto it = g_yolo_ctx.find(c);
-    if (it == g_yolo_ctx.end()) { Y = new YoloContext(); g_yolo_ctx[c] = Y; } else Y = it->second;
+    if (!c->yolo) c->yolo = new YoloContext();
+    Y = c->yolo;
   }
   *out = Y;
   if (Y->B >= B && Y->d_img_bytes >= img_bytes) return 0;
@@ -1567,7 +1564,7 @@ thread_local YoloContext* t_last_yolo = nullptr;
 YoloContext* last_yolo(dani_engine* e) {
   if (!e || !t_last_yolo) return nullptr;
   std::lock_guard<std::mutex> lk(e->mu);
-  for (Context* c : e->ctxs) { auto it = g_yolo_ctx.find(c); if (it != g_yolo_ctx.end() && it->second == t_last_yolo) return t_last_yolo; }
+  for (Context* c : e->ctxs) if (c->yolo && c->yolo == t_last_yolo) return t_last_yolo;
   return nullptr;
 }
 
@@ -1675,26 +1672,21 @@ struct SeqState {
   std::vector<std::string> class_names, dynamic_names;
   float ms[4] = {0, 0, 0, 0};
 };
-std::map<std::pair<dani_engine*, int>, SeqState*> g_seq;
-std::mutex g_seq_mu;
-
 // one SeqState (context + cached previous frame) per (engine, sequence id); id 0 also holds the class lists
 SeqState* seq_state(dani_engine* e, int id = 0) {
-  std::lock_guard<std::mutex> lk(g_seq_mu);
-  auto it = g_seq.find(std::make_pair(e, id));
-  if (it != g_seq.end()) return it->second;
+  std::lock_guard<std::mutex> lk(e->mu);
+  auto it = e->seqs.find(id);
+  if (it != e->seqs.end()) return it->second;
   SeqState* s = new SeqState();
-  g_seq[std::make_pair(e, id)] = s;
+  e->seqs[id] = s;
   return s;
 }
 thread_local SeqState* t_last_seq = nullptr;
 
 void seq_release(dani_engine* e) {
-  std::lock_guard<std::mutex> lk(g_seq_mu);
-  for (auto it = g_seq.begin(); it != g_seq.end();) {
-    if (it->first.first == e) { if (t_last_seq == it->second) t_last_seq = nullptr; delete it->second; it = g_seq.erase(it); }
-    else ++it;
-  }
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (auto& kv : e->seqs) { if (t_last_seq == kv.second) t_last_seq = nullptr; delete kv.second; }
+  e->seqs.clear();
 }
 
 }  // namespace
@@ -1722,9 +1714,9 @@ int dani_frontend_reset(dani_engine* e, int32_t sequence) {
 int dani_frontend_timings(dani_engine* e, float* ms4) {
   if (!e || !ms4 || !t_last_seq) return DANI_ERR_INVALID;
   {
-    std::lock_guard<std::mutex> lk(g_seq_mu);
+    std::lock_guard<std::mutex> lk(e->mu);
     bool mine = false;
-    for (auto& kv : g_seq) mine = mine || (kv.first.first == e && kv.second == t_last_seq);
+    for (auto& kv : e->seqs) mine = mine || kv.second == t_last_seq;
     if (!mine) return DANI_ERR_INVALID;
   }
   for (int i = 0; i < 4; i++) ms4[i] = t_last_seq->ms[i];
