@@ -89,6 +89,8 @@ struct Context {
   float layer_ms[12] = {};
   std::vector<void*> dev_allocs, host_allocs;
   bool busy = false;
+  char* scan_ws = nullptr;              // grow-only workspace of dani_desc_best2
+  size_t scan_ws_bytes = 0;
   struct LgContext* lg = nullptr;       // LightGlue / YOLO workspaces of this context (created on first use, owned)
   struct YoloContext* yolo = nullptr;
 };
@@ -427,6 +429,7 @@ void dani_engine_destroy(dani_engine* e) {
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->lev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : {c->ev_desc, c->ev_y0, c->ev_y1, c->ev_lg0, c->ev_lg1}) if (ev) (void)hipEventDestroy(ev);
+    if (c->scan_ws) (void)hipFree(c->scan_ws);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     delete c;
@@ -1876,10 +1879,14 @@ extern "C" int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, 
   hipStream_t s = c->stream;
   const size_t bq = (size_t)nq * 1024, bt = (size_t)std::max(nt, 1) * 1024, bl = (size_t)std::max(nt, 1) * 4;
   const size_t bo = (size_t)(nq + 1) * 4, bc = (size_t)std::max(total, 1) * 4, bout = (size_t)nq * 4;
-  char* d = nullptr;
   const size_t need = bq + bt + bl + bo + bc + 5 * bout;
-  HIP_TRY(e, hipMalloc((void**)&d, need));
-  struct Free { char* p; ~Free() { (void)hipFree(p); } } fr{d};
+  if (need > c->scan_ws_bytes) {   // grow-only: a tracking thread calls this every frame with similar sizes
+    if (c->scan_ws) (void)hipFree(c->scan_ws);
+    c->scan_ws = nullptr; c->scan_ws_bytes = 0;
+    HIP_TRY(e, hipMalloc((void**)&c->scan_ws, need + need / 4));
+    c->scan_ws_bytes = need + need / 4;
+  }
+  char* d = c->scan_ws;
   float* dq = (float*)d; float* dt = (float*)(d + bq); int32_t* dl = (int32_t*)(d + bq + bt);
   int32_t* doff = (int32_t*)(d + bq + bt + bl); int32_t* dci = (int32_t*)(d + bq + bt + bl + bo);
   char* o = d + bq + bt + bl + bo + bc;

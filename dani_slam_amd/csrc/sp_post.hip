@@ -414,16 +414,35 @@ __global__ __launch_bounds__(64) void desc_best2_kernel(const float* q, const fl
   float bd = 256.0f, bd2 = 256.0f;
   int bl = -1, bl2 = -1, bi = -1;
   const int c0 = cand_off[qi], c1 = cand_off[qi + 1];
-  for (int c = c0; c < c1; c++) {
-    const int idx = cand_idx[c];
-    const float4 b = reinterpret_cast<const float4*>(t + (size_t)idx * 256)[lane];
+  // one candidate: float difference, double accumulation (4 per lane, then the wave tree), sqrt, strict-< bookkeeping
+  auto sq = [&](const float4& b) {
     const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-    double s = (double)d0 * (double)d0 + (double)d1 * (double)d1 + (double)d2 * (double)d2 + (double)d3 * (double)d3;
-    s = wave_sum_f64(s);
-    const float dist = (float)sqrt(s);
+    return (double)d0 * (double)d0 + (double)d1 * (double)d1 + (double)d2 * (double)d2 + (double)d3 * (double)d3;
+  };
+  auto visit = [&](double ssum, int idx) {
+    const float dist = (float)sqrt(ssum);
     const int lvl = t_level ? t_level[idx] : 0;
     if (dist < bd) { bd2 = bd; bd = dist; bl2 = bl; bl = lvl; bi = idx; }
     else if (dist < bd2) { bl2 = lvl; bd2 = dist; }
+  };
+  int c = c0;
+  // four candidate rows in flight per wave (the scan is latency bound: rows come from L2); visited in list order
+  for (; c + 4 <= c1; c += 4) {
+    int idx[4];
+    float4 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) idx[u] = cand_idx[c + u];
+#pragma unroll
+    for (int u = 0; u < 4; u++) b[u] = reinterpret_cast<const float4*>(t + (size_t)idx[u] * 256)[lane];
+    double sv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) sv[u] = wave_sum_f64(sq(b[u]));
+#pragma unroll
+    for (int u = 0; u < 4; u++) visit(sv[u], idx[u]);
+  }
+  for (; c < c1; c++) {
+    const int idx = cand_idx[c];
+    visit(wave_sum_f64(sq(reinterpret_cast<const float4*>(t + (size_t)idx * 256)[lane])), idx);
   }
   if (lane == 0) {
     best_dist[qi] = bd; best_dist2[qi] = bd2; best_idx[qi] = bi; best_level[qi] = bl; best_level2[qi] = bl2;
