@@ -216,11 +216,21 @@ Context* last_ctx(dani_engine* e) {
   for (Context* x : e->ctxs) if (x == c) return c;
   return nullptr;
 }
-thread_local Context* t_borrowed = nullptr;     // set by dani_frontend_batch: nested ABI calls reuse its context
-thread_local bool t_keep_desc_on_device = false;
-thread_local int t_sp_phase = 0;          // 0: whole extractor; 1: enqueue the network only; 2: everything after it
-thread_local bool t_alt_stream = false;   // YOLO on the context's second stream
-thread_local bool t_defer_desc_sync = false;  // fused call: descriptor D2H runs on stream2 under LightGlue
+// How the fused front-end (dani_frontend_batch) drives the three stages; the public ABI entry points pass the defaults.
+struct SpCall {
+  Context* ctx = nullptr;             // run on this context (the sequence's own) instead of acquiring a free one
+  int phase = 0;                      // 0: whole extractor; 1: enqueue the network only; 2: everything after it
+  bool keep_desc_on_device = false;   // `desc` may be null: descriptors are consumed on the device (LightGlue)
+  bool defer_desc_sync = false;       // descriptor read-back into pinned staging on stream2, no final synchronise
+};
+struct YoloCall {
+  Context* ctx = nullptr;
+  bool alt_stream = false;            // run on the context's second (high-priority) stream, next to the SuperPoint network
+};
+struct LgCall {
+  Context* ctx = nullptr;
+  std::function<void()>* overlap = nullptr;   // host work of the caller to run while the forward pass executes
+};
 
 // stream2 carries YOLO's ~70 small dependent kernels while the main stream runs SuperPoint's few huge ones: give it
 // the highest priority so that its workgroups get the CU slots that free up first (otherwise the chain starves
@@ -232,17 +242,24 @@ hipError_t create_priority_stream(hipStream_t* s) {
 }
 
 Context* acquire(dani_engine* e) {
-  if (t_borrowed) return t_borrowed;
   std::lock_guard<std::mutex> lk(e->mu);
   for (Context* c : e->ctxs)
     if (!c->busy) { c->busy = true; return c; }
   return nullptr;
 }
 void release(dani_engine* e, Context* c) {
-  if (c == t_borrowed) return;
   std::lock_guard<std::mutex> lk(e->mu);
   c->busy = false;
 }
+
+// a context for one call: the caller's own (fused front-end) or a free one from the pool, released on scope exit
+struct CtxLease {
+  dani_engine* e; Context* c; bool owned;
+  CtxLease(dani_engine* e_, Context* given) : e(e_), c(given ? given : acquire(e_)), owned(!given) {}
+  ~CtxLease() { if (owned && c) release(e, c); }
+  CtxLease(const CtxLease&) = delete;
+  CtxLease& operator=(const CtxLease&) = delete;
+};
 
 int dev_alloc(dani_engine* e, Context* c, void** p, size_t bytes, bool zero) {
   HIP_TRY(e, hipMalloc(p, bytes));
@@ -525,21 +542,25 @@ int dani_set_profiling(dani_engine* e, int on) {
   return DANI_OK;
 }
 
-int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_device, int32_t B, int32_t W, int32_t H,
-                          int32_t stride, const dani_sp_params* p, const int32_t* boxes, const int32_t* box_offsets,
-                          const int32_t lapping[2], float* kpts_xy, float* resp, int32_t* octave, float* size,
-                          float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index) {
+}  // extern "C"
+
+namespace {
+
+int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int32_t imgs_on_device, int32_t B, int32_t W, int32_t H,
+                    int32_t stride, const dani_sp_params* p, const int32_t* boxes, const int32_t* box_offsets,
+                    const int32_t lapping[2], float* kpts_xy, float* resp, int32_t* octave, float* size,
+                    float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index) {
   if (!e) return DANI_ERR_INVALID;
   if (!imgs || W <= 0 || H <= 0) return fail(e, DANI_ERR_EMPTY, "empty image");
   if (!e->finalized) return fail(e, DANI_ERR_WEIGHTS, "weights not finalized (call dani_finalize_weights)");
   if (B < 1 || B > e->cfg.max_batch) return fail(e, DANI_ERR_INVALID, "batch %d outside [1, %d]", B, e->cfg.max_batch);
-  if (stride < W || cap < 1 || !n_out || !kpts_xy || !resp || (!desc && !t_keep_desc_on_device)) return fail(e, DANI_ERR_INVALID, "bad argument");
+  if (stride < W || cap < 1 || !n_out || !kpts_xy || !resp || (!desc && !call.keep_desc_on_device)) return fail(e, DANI_ERR_INVALID, "bad argument");
   int rc = check_params(e, W, H, p);
   if (rc) return rc;
   HIP_TRY(e, hipSetDevice(e->device));
-  Context* c = acquire(e);
+  CtxLease lease(e, call.ctx);
+  Context* c = lease.c;
   if (!c) return fail(e, DANI_ERR_INVALID, "all %d contexts busy (raise dani_config.n_contexts)", e->cfg.n_contexts);
-  struct Releaser { dani_engine* e; Context* c; ~Releaser() { release(e, c); } } rel{e, c};
   t_last_ctx = c;
   std::vector<int> per_level; std::vector<float> scales;
   features_per_level(p->nfeatures, p->scale_factor, p->nlevels, per_level, scales);
@@ -551,7 +572,7 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
   const int MB = e->cfg.max_batch;
 
   const bool prof = e->profiling;
-  const int phase = t_sp_phase;
+  const int phase = call.phase;
   if (phase != 2) {
     // ---- inputs
     const uint8_t* dimg = imgs;
@@ -701,15 +722,27 @@ int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_d
     // caller moves it to `desc` while LightGlue runs
     for (int b = 0; b < B; b++)
       if (n_out[b])
-        HIP_TRY(e, hipMemcpyAsync(t_defer_desc_sync ? c->h_desc + (size_t)b * c->kcap * 256 : desc + (size_t)b * cap * 256,
+        HIP_TRY(e, hipMemcpyAsync(call.defer_desc_sync ? c->h_desc + (size_t)b * c->kcap * 256 : desc + (size_t)b * cap * 256,
                                   c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, c->stream2));
-    if (!t_defer_desc_sync) HIP_TRY(e, hipStreamSynchronize(c->stream2));
+    if (!call.defer_desc_sync) HIP_TRY(e, hipStreamSynchronize(c->stream2));
   }
   HIP_TRY(e, hipGetLastError());
-  if (t_defer_desc_sync) return DANI_OK;   // the fused call synchronises (and reads the timers) after LightGlue
+  if (call.defer_desc_sync) return DANI_OK;   // the fused call synchronises (and reads the timers) after LightGlue
   HIP_TRY(e, hipStreamSynchronize(s));
   sp_read_timers(c, prof);
   return DANI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dani_sp_extract_batch(dani_engine* e, const uint8_t* imgs, int32_t imgs_on_device, int32_t B, int32_t W, int32_t H,
+                          int32_t stride, const dani_sp_params* p, const int32_t* boxes, const int32_t* box_offsets,
+                          const int32_t lapping[2], float* kpts_xy, float* resp, int32_t* octave, float* size,
+                          float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index) {
+  return sp_extract_impl(e, SpCall{}, imgs, imgs_on_device, B, W, H, stride, p, boxes, box_offsets, lapping, kpts_xy, resp, octave,
+                         size, desc, cap, n_out, mono_index);
 }
 
 int dani_sp_extract(dani_engine* e, const uint8_t* img, int32_t W, int32_t H, int32_t stride, const dani_sp_params* p,
@@ -1087,16 +1120,19 @@ LgContext* last_lg(dani_engine* e) {
   for (Context* c : e->ctxs) if (c->lg && c->lg == t_last_lg) return t_last_lg;
   return nullptr;
 }
-thread_local std::function<void()>* t_overlap_fn = nullptr;   // set by the fused front-end around its LightGlue call
 
 }  // namespace
 
 extern "C" {
 
-int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_device, const float* kpts0,
-                        const float* desc0, const int32_t* n0, const float* kpts1, const float* desc1, const int32_t* n1,
-                        const float* size0, const float* size1, float threshold, int32_t* matches, float* scores,
-                        int32_t cap, int32_t* k_out) {
+}  // extern "C"
+
+namespace {
+
+int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap, int32_t on_device, const float* kpts0,
+                  const float* desc0, const int32_t* n0, const float* kpts1, const float* desc1, const int32_t* n1,
+                  const float* size0, const float* size1, float threshold, int32_t* matches, float* scores,
+                  int32_t cap, int32_t* k_out) {
   if (!e) return DANI_ERR_INVALID;
   if (P < 1 || !n0 || !n1 || !kpts0 || !kpts1 || !desc0 || !desc1 || !matches || !scores || !k_out || cap < 1 || in_cap < 1)
     return fail(e, DANI_ERR_INVALID, "bad dani_lg_match argument");
@@ -1108,9 +1144,9 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
     kmax = std::max(kmax, std::max(n0[p], n1[p]));
   }
   HIP_TRY(e, hipSetDevice(e->device));
-  Context* c = acquire(e);
+  CtxLease lease(e, call.ctx);
+  Context* c = lease.c;
   if (!c) return fail(e, DANI_ERR_INVALID, "all contexts busy");
-  struct Releaser { dani_engine* e; Context* c; ~Releaser() { release(e, c); } } rel{e, c};
   LgContext* L = nullptr;
   int rc = lg_ensure(e, c, &L, P, kmax);
   if (rc) return rc;
@@ -1188,7 +1224,7 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
   HIP_TRY(e, hipEventRecord(c->ev_lg1, s));
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemcpy2DAsync(L->h_m0, (size_t)L->ld * 4, L->m0, (size_t)L->ld * 4, (size_t)doff * 4, 3, hipMemcpyDeviceToHost, s));
-  if (t_overlap_fn) { (*t_overlap_fn)(); }   // host work of the caller that can run under the forward pass
+  if (call.overlap) (*call.overlap)();   // host work of the caller that can run under the forward pass
   HIP_TRY(e, hipStreamSynchronize(s));
   (void)hipEventElapsedTime(&c->ms[0], c->ev_lg0, c->ev_lg1);
   c->ms[4] = c->ms[0];
@@ -1228,6 +1264,18 @@ int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_de
   }
   if (status != DANI_OK) return fail(e, status, "match capacity %d too small", cap);
   return DANI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_device, const float* kpts0,
+                        const float* desc0, const int32_t* n0, const float* kpts1, const float* desc1, const int32_t* n1,
+                        const float* size0, const float* size1, float threshold, int32_t* matches, float* scores,
+                        int32_t cap, int32_t* k_out) {
+  return lg_match_impl(e, LgCall{}, P, in_cap, on_device, kpts0, desc0, n0, kpts1, desc1, n1, size0, size1, threshold, matches, scores,
+                       cap, k_out);
 }
 
 int dani_lg_match(dani_engine* e, const float* kpts0, const float* desc0, int32_t n0, const float* kpts1,
@@ -1575,23 +1623,27 @@ YoloContext* last_yolo(dani_engine* e) {
 
 extern "C" {
 
-int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device, int32_t B, int32_t W, int32_t H,
-                           int32_t stride, float score_thresh, float iou_thresh, float* dets6, int32_t cap, int32_t* n_out) {
+}  // extern "C"
+
+namespace {
+
+int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, int32_t on_device, int32_t B, int32_t W, int32_t H,
+                     int32_t stride, float score_thresh, float iou_thresh, float* dets6, int32_t cap, int32_t* n_out) {
   if (!e) return DANI_ERR_INVALID;
   if (!bgr || W <= 0 || H <= 0) return fail(e, DANI_ERR_EMPTY, "Read RGB failed!");   // src/YoloDetect.cpp:32-36
   if (B < 1 || B > e->cfg.max_batch || stride < 3 * W || !dets6 || !n_out || cap < 1) return fail(e, DANI_ERR_INVALID, "bad dani_yolo_detect argument");
   YoloWeights* Wt = yolo_weights(e);
   if (!e->finalized || !Wt->ready) return fail(e, DANI_ERR_WEIGHTS, "YOLO weights not loaded/finalized");
   HIP_TRY(e, hipSetDevice(e->device));
-  Context* c = acquire(e);
+  CtxLease lease(e, call.ctx);
+  Context* c = lease.c;
   if (!c) return fail(e, DANI_ERR_INVALID, "all contexts busy");
-  struct Releaser { dani_engine* e; Context* c; ~Releaser() { release(e, c); } } rel{e, c};
   YoloContext* Y = nullptr;
   const size_t fbytes = (size_t)H * stride;
   int rc = yolo_ensure(e, c, &Y, e->cfg.max_batch, fbytes * e->cfg.max_batch);
   if (rc) return rc;
   t_last_yolo = Y; t_last_ctx = c;
-  hipStream_t s = t_alt_stream ? c->stream2 : c->stream;
+  hipStream_t s = call.alt_stream ? c->stream2 : c->stream;
   const uint8_t* dimg = bgr;
   if (!on_device) {
     HIP_TRY(e, hipMemcpyAsync(Y->d_img, bgr, fbytes * B, hipMemcpyHostToDevice, s));
@@ -1618,7 +1670,7 @@ int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device
     }
   }
   if (more) HIP_TRY(e, hipStreamSynchronize(s));
-  if (!t_alt_stream) { (void)hipEventElapsedTime(&c->ms[0], c->ev_y0, c->ev_y1); c->ms[4] = c->ms[0]; }
+  if (!call.alt_stream) { (void)hipEventElapsedTime(&c->ms[0], c->ev_y0, c->ev_y1); c->ms[4] = c->ms[0]; }
   int status = DANI_OK;
   // greedy NMS is O(k n) per frame and independent across frames
   host_pool().run(B, [&](int b) {
@@ -1628,6 +1680,15 @@ int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device
     if (n_out[b] > cap) status = DANI_ERR_CAPACITY;
   if (status != DANI_OK) return fail(e, status, "detection capacity %d too small", cap);
   return DANI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dani_yolo_detect_batch(dani_engine* e, const uint8_t* bgr, int32_t on_device, int32_t B, int32_t W, int32_t H,
+                           int32_t stride, float score_thresh, float iou_thresh, float* dets6, int32_t cap, int32_t* n_out) {
+  return yolo_detect_impl(e, YoloCall{}, bgr, on_device, B, W, H, stride, score_thresh, iou_thresh, dets6, cap, n_out);
 }
 
 int dani_yolo_detect(dani_engine* e, const uint8_t* bgr, int32_t W, int32_t H, int32_t stride, float score_thresh,
@@ -1759,7 +1820,6 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     S->ctx = c;
   }
   Context* c = S->ctx;
-  struct Borrow { Borrow(Context* c) { t_borrowed = c; } ~Borrow() { t_borrowed = nullptr; t_keep_desc_on_device = false; } } borrow(c);
   t_last_seq = S;
   const auto t0 = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
@@ -1768,23 +1828,22 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   //         while YOLO's ~70 small kernels run on the second stream fills the CUs those leave idle
   std::vector<int32_t> octave((size_t)B * cap);
   std::vector<float> size((size_t)B * cap);
-  t_keep_desc_on_device = true;
-  t_sp_phase = 1;
-  int rc = dani_sp_extract_batch(e, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
-                                 octave.data(), size.data(), desc, cap, n_out, mono_index);
-  t_sp_phase = 0;
-  if (rc) { t_keep_desc_on_device = false; return rc; }
+  SpCall sp_call;
+  sp_call.ctx = c; sp_call.keep_desc_on_device = true; sp_call.phase = 1;
+  int rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
+                           octave.data(), size.data(), desc, cap, n_out, mono_index);
+  if (rc) return rc;
 
   // ---- 1. YOLO -> dynamic boxes (Tracking.cc:1535-1539)
   std::vector<int32_t> boxes, offs(B + 1, 0);
   if (p->use_yolo) {
-    t_alt_stream = true;
-    struct AltOff { ~AltOff() { t_alt_stream = false; } } alt_off;
+    YoloCall yolo_call;
+    yolo_call.ctx = c; yolo_call.alt_stream = true;
     const int dcap = 4096;
     std::vector<float> dets((size_t)B * dcap * 6);
     std::vector<int32_t> nd(B);
-    rc = dani_yolo_detect_batch(e, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
-    if (rc) { t_keep_desc_on_device = false; return rc; }
+    rc = yolo_detect_impl(e, yolo_call, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
+    if (rc) return rc;
     std::vector<const char*> cn, dn;
     for (auto& s : class_names) cn.push_back(s.c_str());
     for (auto& s : dynamic_names) dn.push_back(s.c_str());
@@ -1796,7 +1855,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     for (int b = 0; b < B; b++) {
       const int k = kk[b];
       n_boxes[b] = k;
-      if (k > box_cap) { t_keep_desc_on_device = false; return fail(e, DANI_ERR_CAPACITY, "frame %d has %d dynamic boxes (> %d)", b, k, box_cap); }
+      if (k > box_cap) { return fail(e, DANI_ERR_CAPACITY, "frame %d has %d dynamic boxes (> %d)", b, k, box_cap); }
       memcpy(dyn_boxes + (size_t)b * box_cap * 4, tmp[b].data(), (size_t)k * 16);
       boxes.insert(boxes.end(), tmp[b].begin(), tmp[b].begin() + (size_t)k * 4);
       offs[b + 1] = offs[b] + k;
@@ -1808,14 +1867,10 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
 
   // ---- 2. SuperPoint with the boxes as mvDynamicArea; descriptors stay resident for LightGlue
   const auto t1 = std::chrono::steady_clock::now();
-  t_sp_phase = 2;
-  t_defer_desc_sync = true;
-  rc = dani_sp_extract_batch(e, gray, on_device, B, W, H, gray_stride, &p->sp, boxes.empty() ? nullptr : boxes.data(),
-                             boxes.empty() ? nullptr : offs.data(), p->lapping, kpts_xy, resp, octave.data(), size.data(),
-                             desc, cap, n_out, mono_index);
-  t_sp_phase = 0;
-  t_defer_desc_sync = false;
-  t_keep_desc_on_device = false;
+  sp_call.phase = 2; sp_call.defer_desc_sync = true;
+  rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, boxes.empty() ? nullptr : boxes.data(),
+                       boxes.empty() ? nullptr : offs.data(), p->lapping, kpts_xy, resp, octave.data(), size.data(),
+                       desc, cap, n_out, mono_index);
   if (rc) return rc;
   S->ms[1] = ms_since(t1);
 
@@ -1836,10 +1891,10 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     std::vector<int32_t> n0(B), n1(B);
     for (int b = 0; b < B; b++) { n0[b] = b ? n_out[b - 1] : c->prev_n; n1[b] = n_out[b]; }
     const float sz[2] = {(float)W, (float)H};
-    t_overlap_fn = &move_desc;
-    rc = dani_lg_match_batch(e, B, c->kcap, 1, c->d_kxy_all, c->d_desc_all, n0.data(), c->d_kxy, c->d_descout, n1.data(), sz, sz,
+    LgCall lg_call;
+    lg_call.ctx = c; lg_call.overlap = &move_desc;
+    rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kxy_all, c->d_desc_all, n0.data(), c->d_kxy, c->d_descout, n1.data(), sz, sz,
                              p->lg_threshold, matches, scores, match_cap, k_out);
-    t_overlap_fn = nullptr;
     if (rc) { move_desc(); (void)hipStreamSynchronize(c->stream); return rc; }
   }
   // cache the last frame's features as the next call's predecessor
