@@ -54,3 +54,37 @@ def test_sequence_matches_oracle_composition(weights, sp_weights):
     ref = oracle.sp_extract(gray[0], sp_weights, nfeatures=NF)
     assert np.array_equal(o3[0]["kpts"], ref["kpts"])
     e.close()
+
+
+def test_frames_without_keypoints(weights, sp_weights):
+    """A call whose frames yield no keypoint at all (thresholds nothing passes): empty keypoint sets flow through the
+    cull, the descriptor stage and LightGlue; the following call sees an empty predecessor and reports no matches."""
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=2, weights=weights)
+    e.yolo_set_classes(yo.COCO_NAMES, yo.DYNAMIC_NAMES)
+    gray = np.stack([synth.frame(0), synth.frame(1)]); bgr = np.stack([synth.frame_bgr(0), synth.frame_bgr(1)])
+    first = e.frontend_batch(gray, bgr, nfeatures=NF)
+    assert len(first[1]["matches"]) > 10
+    empty = e.frontend_batch(gray, bgr, nfeatures=NF, iniTh=0.9999, minTh=0.9999)
+    for i in range(2):
+        assert len(empty[i]["kpts"]) == 0 and empty[i]["desc"].shape == (0, 256) and len(empty[i]["matches"]) == 0
+        ok, dets, dyn, dmap = yo.detect(weights, bgr[i])
+        assert [tuple(int(v) for v in r) for r in empty[i]["boxes"]] == [tuple(r) for r in dyn]      # YOLO is unaffected
+    again = e.frontend_batch(gray, bgr, nfeatures=NF)
+    assert len(again[0]["matches"]) == 0                       # predecessor = the empty frame
+    assert np.array_equal(again[1]["matches"], first[1]["matches"]) and np.array_equal(again[1]["kpts"], first[1]["kpts"])
+    e.close()
+
+
+def test_capacity_errors_are_reported(weights):
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=2, weights=weights)
+    e.yolo_set_classes(yo.COCO_NAMES, yo.DYNAMIC_NAMES)
+    gray = np.stack([synth.frame(0), synth.frame(1)]); bgr = np.stack([synth.frame_bgr(0), synth.frame_bgr(1)])
+    with pytest.raises(frontend.DaniError):
+        e.frontend_batch(gray, bgr, nfeatures=NF, box_cap=1)      # frame 1 yields more than one dynamic box
+    out = e.frontend_batch(gray, bgr, nfeatures=NF)               # the engine stays usable after the error
+    assert len(out[0]["kpts"]) > 100
+    with pytest.raises(frontend.DaniError):
+        e.frontend_batch(np.stack([gray[0]] * 3), np.stack([bgr[0]] * 3), nfeatures=NF)   # batch above max_batch
+    e.close()
