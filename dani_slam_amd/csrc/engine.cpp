@@ -226,6 +226,7 @@ struct SpCall {
 struct YoloCall {
   Context* ctx = nullptr;
   bool alt_stream = false;            // run on the context's second (high-priority) stream, next to the SuperPoint network
+  std::function<void(int, const float*, int)>* post = nullptr;   // per frame, inside the NMS worker: (frame, dets6, n)
 };
 struct LgCall {
   Context* ctx = nullptr;
@@ -1675,6 +1676,7 @@ int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, i
   // greedy NMS is O(k n) per frame and independent across frames
   host_pool().run(B, [&](int b) {
     n_out[b] = yolo_nms_host(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->h_count[b], iou_thresh, dets6 + (size_t)b * cap * 6, cap);
+    if (call.post && n_out[b] <= cap) (*call.post)(b, dets6 + (size_t)b * cap * 6, n_out[b]);
   });
   for (int b = 0; b < B; b++)
     if (n_out[b] > cap) status = DANI_ERR_CAPACITY;
@@ -1735,6 +1737,9 @@ struct SeqState {
   Context* ctx = nullptr;
   std::vector<std::string> class_names, dynamic_names;
   float ms[4] = {0, 0, 0, 0};
+  // per-call host scratch, kept between calls (a fresh 0.8 MB vector per call costs a memset on the critical path)
+  std::vector<float> dets, size;
+  std::vector<int32_t> octave, frame_boxes;
 };
 // one SeqState (context + cached previous frame) per (engine, sequence id); id 0 also holds the class lists
 SeqState* seq_state(dani_engine* e, int id = 0) {
@@ -1826,8 +1831,9 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
 
   // ---- 0. enqueue the SuperPoint network first: it does not need the boxes, and running it on the main stream
   //         while YOLO's ~70 small kernels run on the second stream fills the CUs those leave idle
-  std::vector<int32_t> octave((size_t)B * cap);
-  std::vector<float> size((size_t)B * cap);
+  std::vector<int32_t>& octave = S->octave;
+  std::vector<float>& size = S->size;
+  if (octave.size() < (size_t)B * cap) { octave.resize((size_t)B * cap); size.resize((size_t)B * cap); }
   SpCall sp_call;
   sp_call.ctx = c; sp_call.keep_desc_on_device = true; sp_call.phase = 1;
   int rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
@@ -1840,24 +1846,28 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     YoloCall yolo_call;
     yolo_call.ctx = c; yolo_call.alt_stream = true;
     const int dcap = 4096;
-    std::vector<float> dets((size_t)B * dcap * 6);
+    std::vector<float>& dets = S->dets;
+    std::vector<int32_t>& tmp = S->frame_boxes;            // per frame: up to dcap + 1 boxes
+    const size_t tstride = (size_t)(dcap + 1) * 4;
+    if (dets.size() < (size_t)B * dcap * 6) { dets.resize((size_t)B * dcap * 6); tmp.resize((size_t)B * tstride); }
     std::vector<int32_t> nd(B);
-    rc = yolo_detect_impl(e, yolo_call, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
-    if (rc) return rc;
     std::vector<const char*> cn, dn;
     for (auto& s : class_names) cn.push_back(s.c_str());
     for (auto& s : dynamic_names) dn.push_back(s.c_str());
-    std::vector<std::vector<int32_t>> tmp(B, std::vector<int32_t>((size_t)(dcap + 1) * 4));
     std::vector<int> kk(B, 0);
-    host_pool().run(B, [&](int b) {
-      kk[b] = yolo_dynamic_areas(dets.data() + (size_t)b * dcap * 6, nd[b], W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp[b].data(), dcap + 1);
-    });
+    // box bookkeeping + RefineDynamicBoxes run in the same worker task as the frame's NMS
+    std::function<void(int, const float*, int)> areas = [&](int b, const float* d6, int n) {
+      kk[b] = yolo_dynamic_areas(d6, n, W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp.data() + (size_t)b * tstride, dcap + 1);
+    };
+    yolo_call.post = &areas;
+    rc = yolo_detect_impl(e, yolo_call, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
+    if (rc) return rc;
     for (int b = 0; b < B; b++) {
       const int k = kk[b];
       n_boxes[b] = k;
       if (k > box_cap) { return fail(e, DANI_ERR_CAPACITY, "frame %d has %d dynamic boxes (> %d)", b, k, box_cap); }
-      memcpy(dyn_boxes + (size_t)b * box_cap * 4, tmp[b].data(), (size_t)k * 16);
-      boxes.insert(boxes.end(), tmp[b].begin(), tmp[b].begin() + (size_t)k * 4);
+      memcpy(dyn_boxes + (size_t)b * box_cap * 4, tmp.data() + (size_t)b * tstride, (size_t)k * 16);
+      boxes.insert(boxes.end(), tmp.begin() + (size_t)b * tstride, tmp.begin() + (size_t)b * tstride + (size_t)k * 4);
       offs[b + 1] = offs[b] + k;
     }
   } else if (n_boxes) {
@@ -1879,7 +1889,15 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   // descriptor read-back: stream2 fills the pinned staging while LightGlue is being launched; the copy into the
   // caller's array then runs on this thread under the forward pass
   bool desc_moved = false;
+  bool cache_enqueued = false;
+  auto enqueue_cache = [&] {   // the last frame's features become the next call's predecessor (slot 0 of the slabs)
+    if (cache_enqueued) return;
+    cache_enqueued = true;
+    (void)hipMemcpyAsync(c->d_kxy_all, c->d_kxy + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream);
+  };
   std::function<void()> move_desc = [&] {
+    enqueue_cache();           // behind the LightGlue kernels in stream order, ahead of the call's final synchronise
     if (desc_moved || !desc) return;
     desc_moved = true;
     if (hipStreamSynchronize(c->stream2) != hipSuccess) return;
@@ -1897,13 +1915,12 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
                              p->lg_threshold, matches, scores, match_cap, k_out);
     if (rc) { move_desc(); (void)hipStreamSynchronize(c->stream); return rc; }
   }
-  // cache the last frame's features as the next call's predecessor
-  HIP_TRY(e, hipMemcpyAsync(c->d_kxy_all, c->d_kxy + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+  const bool synced = cache_enqueued;   // LightGlue ran: its final synchronise covered the cache copies
   move_desc();
-  HIP_TRY(e, hipStreamSynchronize(c->stream));
+  if (!synced) HIP_TRY(e, hipStreamSynchronize(c->stream));
   HIP_TRY(e, hipStreamSynchronize(c->stream2));
-  sp_read_timers(c, e->profiling);
+  HIP_TRY(e, hipGetLastError());
+  if (e->profiling) sp_read_timers(c, true);
   c->prev_n = n_out[B - 1];
   S->ms[2] = ms_since(t2);
   S->ms[3] = ms_since(t0);
