@@ -1,0 +1,246 @@
+// engine_internal.h -- shared state and helpers of the C-ABI implementation (engine.cpp, sp_engine.cpp, lg_engine.cpp,
+// yolo_engine.cpp, frontend_engine.cpp).  Not part of the ABI: include/dani_frontend.h is.
+#pragma once
+#include "../../include/dani_frontend.h"
+
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+using namespace dani;
+
+
+namespace dani {
+namespace eng {
+
+extern thread_local std::string g_create_error;
+
+constexpr int CAND_CAP = 32768;  // candidates per frame kept on the device (reference reserves 10*nfeatures)
+constexpr int CAND_FAST = 4096;  // candidates per frame read back together with the counts (typical frames: 3-4 k)
+
+struct Context {
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // YOLO (concurrent with the SuperPoint conv stack) and overlapped D2H copies
+  hipEvent_t ev_desc = nullptr, ev_y0 = nullptr, ev_y1 = nullptr, ev_lg0 = nullptr, ev_lg1 = nullptr;
+  int W = 0, H = 0, B = 0;  // shapes the buffers are built for
+  int nlevels = 0;
+  float scale_factor = 0.0f;
+  struct Level {              // one pyramid level (ComputePyramid, src/SPextractor.cpp:631-656)
+    int W = 0, H = 0;
+    ActDesc act[12];          // output of layer i (layers 1,3,5: pooled)
+    float* prob = nullptr;
+    float* desc_nhwc = nullptr;
+    float* desc_nchw = nullptr;
+    std::vector<CellRect> cells;
+    CellRect* d_cells = nullptr;
+    int slot_stride = 0;
+    float* slot_xyr = nullptr;
+    int32_t* slot_count = nullptr;
+    float* cand = nullptr;
+    int32_t* cand_count = nullptr;
+    float* h_cand = nullptr;          // pinned
+    int32_t* h_cand_count = nullptr;  // pinned
+    uint8_t* d_level_img = nullptr;   // level > 0: this level's image [B][H][W] (resized from level - 1)
+  };
+  std::vector<Level> lv;
+  int32_t* d_boxes = nullptr;
+  int32_t* d_box_offsets = nullptr;
+  int box_cap = 0;
+  uint8_t* d_img = nullptr;
+  size_t d_img_bytes = 0;
+  float* d_kxy_all = nullptr;
+  float* d_desc_all = nullptr;
+  int prev_n = 0;            // keypoints of the cached previous frame (slot 0)
+  float* d_kxy = nullptr;
+  int32_t* d_nk = nullptr;
+  float* d_sampled = nullptr;
+  float* d_descout = nullptr;
+  int kcap = 0;
+  // pinned host staging
+  float* h_kxy = nullptr;  // [B][kcap][2] followed by per-level (offset, count) ints [nlevels][2][B]
+  float* h_desc = nullptr; // [B][kcap][256]: descriptor read-back of the fused call (copied out under LightGlue)
+  int32_t* h_boxes = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t lev[13] = {};
+  float ms[5] = {0, 0, 0, 0, 0};
+  float layer_ms[12] = {};
+  std::vector<void*> dev_allocs, host_allocs;
+  bool busy = false;
+  char* scan_ws = nullptr;              // grow-only workspace of dani_desc_best2
+  size_t scan_ws_bytes = 0;
+  struct LgContext* lg = nullptr;       // LightGlue / YOLO workspaces of this context (created on first use, owned)
+  struct YoloContext* yolo = nullptr;
+};
+
+struct LgWeights;
+struct YoloWeights;
+struct SeqState;
+
+
+}  // namespace eng
+}  // namespace dani
+
+struct dani_engine {
+  dani_config cfg;
+  int device = 0;
+  std::string err;
+  std::map<std::string, std::vector<float>> tensors;
+  bool finalized = false;
+  ConvLayerPlan plan[12];
+  float* w1a = nullptr;
+  float* b1a = nullptr;
+  std::vector<void*> weight_allocs;
+  std::vector<dani::eng::Context*> ctxs;
+  std::mutex mu;
+  bool profiling = false;
+  dani::eng::LgWeights* lgw = nullptr;             // packed LightGlue / YOLO weights (owned; device buffers are in weight_allocs)
+  dani::eng::YoloWeights* yw = nullptr;
+  std::map<int, dani::eng::SeqState*> seqs;        // dani_frontend_batch sequences (own context + cached previous frame), under mu
+};
+
+
+namespace dani {
+namespace eng {
+
+int fail(dani_engine* e, int code, const char* fmt, ...);
+
+#define HIP_TRY(e, call)                                                                            \
+  do {                                                                                              \
+    hipError_t _st = (call);                                                                        \
+    if (_st != hipSuccess)                                                                          \
+      return fail((e), DANI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_st), __FILE__, __LINE__); \
+  } while (0)
+
+// Small persistent worker pool for the per-frame host stages (quadtree, NMS, box refinement): one pool per calling
+// thread, so concurrent sequences never share one.  Spawning std::threads per call cost ~150 us per stage.
+class HostPool {
+ public:
+  explicit HostPool(int workers) {
+    for (int i = 0; i < workers; i++) th_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // runs fn(0..count-1); the caller takes part; returns when all are done
+  void run(int count, const std::function<void(int)>& fn) {
+    if (count <= 1 || th_.empty()) { for (int i = 0; i < count; i++) fn(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; count_ = count; next_ = 0; remaining_ = count; gen_++;
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return remaining_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      int i;
+      const std::function<void(int)>* f;
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!fn_ || next_ >= count_) return;
+        i = next_++; f = fn_;
+      }
+      (*f)(i);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--remaining_ == 0) done_.notify_all();
+      }
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int count_ = 0, next_ = 0, remaining_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+HostPool& host_pool();   // one pool per calling thread
+
+extern thread_local Context* t_last_ctx;
+Context* last_ctx(dani_engine* e);   // the calling thread's last context, if it still belongs to engine e
+
+// How the fused front-end (dani_frontend_batch) drives the three stages; the public ABI entry points pass the defaults.
+struct SpCall {
+  Context* ctx = nullptr;             // run on this context (the sequence's own) instead of acquiring a free one
+  int phase = 0;                      // 0: whole extractor; 1: enqueue the network only; 2: everything after it
+  bool keep_desc_on_device = false;   // `desc` may be null: descriptors are consumed on the device (LightGlue)
+  bool defer_desc_sync = false;       // descriptor read-back into pinned staging on stream2, no final synchronise
+};
+struct YoloCall {
+  Context* ctx = nullptr;
+  bool alt_stream = false;            // run on the context's second (high-priority) stream, next to the SuperPoint network
+  std::function<void(int, const float*, int)>* post = nullptr;   // per frame, inside the NMS worker: (frame, dets6, n)
+};
+struct LgCall {
+  Context* ctx = nullptr;
+  std::function<void()>* overlap = nullptr;   // host work of the caller to run while the forward pass executes
+};
+
+hipError_t create_priority_stream(hipStream_t* s);
+Context* acquire(dani_engine* e);
+void release(dani_engine* e, Context* c);
+
+// a context for one call: the caller's own (fused front-end) or a free one from the pool, released on scope exit
+struct CtxLease {
+  dani_engine* e; Context* c; bool owned;
+  CtxLease(dani_engine* e_, Context* given) : e(e_), c(given ? given : acquire(e_)), owned(!given) {}
+  ~CtxLease() { if (owned && c) release(e, c); }
+  CtxLease(const CtxLease&) = delete;
+  CtxLease& operator=(const CtxLease&) = delete;
+};
+
+int dev_alloc(dani_engine* e, Context* c, void** p, size_t bytes, bool zero);
+int host_alloc(dani_engine* e, Context* c, void** p, size_t bytes);
+void free_buffers(Context* c);
+
+// stage implementations (the ABI entry points pass default call options; dani_frontend_batch drives them explicitly)
+int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int32_t imgs_on_device, int32_t B, int32_t W, int32_t H,
+                    int32_t stride, const dani_sp_params* p, const int32_t* boxes, const int32_t* box_offsets,
+                    const int32_t lapping[2], float* kpts_xy, float* resp, int32_t* octave, float* size,
+                    float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index);
+int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap, int32_t on_device, const float* kpts0,
+                  const float* desc0, const int32_t* n0, const float* kpts1, const float* desc1, const int32_t* n1,
+                  const float* size0, const float* size1, float threshold, int32_t* matches, float* scores,
+                  int32_t cap, int32_t* k_out);
+int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, int32_t on_device, int32_t B, int32_t W, int32_t H,
+                     int32_t stride, float score_thresh, float iou_thresh, float* dets6, int32_t cap, int32_t* n_out);
+void sp_read_timers(Context* c, bool prof);
+int lg_finalize(dani_engine* e);     // pack the LightGlue / YOLO tensors of e->tensors (dani_finalize_weights, sp_engine.cpp)
+int yolo_finalize(dani_engine* e);
+void lg_release(dani_engine* e);     // workspaces and packed weights die with the engine
+void yolo_release(dani_engine* e);
+void seq_release(dani_engine* e);
+
+}  // namespace eng
+}  // namespace dani

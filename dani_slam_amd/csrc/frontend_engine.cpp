@@ -1,0 +1,260 @@
+// frontend_engine.cpp -- the fused per-frame front-end (sequence mode) and the projection-search descriptor scans.
+#include "engine_internal.h"
+
+using namespace dani;
+using namespace dani::eng;
+
+// ================================================================================================
+// Fused per-frame front-end (sequence mode)
+// ================================================================================================
+namespace dani {
+namespace eng {
+
+struct SeqState {
+  std::mutex mu;
+  Context* ctx = nullptr;
+  std::vector<std::string> class_names, dynamic_names;
+  float ms[4] = {0, 0, 0, 0};
+  // per-call host scratch, kept between calls (a fresh 0.8 MB vector per call costs a memset on the critical path)
+  std::vector<float> dets, size;
+  std::vector<int32_t> octave, frame_boxes;
+};
+// one SeqState (context + cached previous frame) per (engine, sequence id); id 0 also holds the class lists
+SeqState* seq_state(dani_engine* e, int id = 0) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  auto it = e->seqs.find(id);
+  if (it != e->seqs.end()) return it->second;
+  SeqState* s = new SeqState();
+  e->seqs[id] = s;
+  return s;
+}
+thread_local SeqState* t_last_seq = nullptr;
+
+void seq_release(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (auto& kv : e->seqs) { if (t_last_seq == kv.second) t_last_seq = nullptr; delete kv.second; }
+  e->seqs.clear();
+}
+
+}  // namespace eng
+}  // namespace dani
+
+extern "C" {
+
+int dani_yolo_set_classes(dani_engine* e, const char* const* class_names, int32_t n_classes,
+                          const char* const* dynamic_names, int32_t n_dynamic) {
+  if (!e || !class_names || !dynamic_names || n_classes < 1 || n_dynamic < 0) return fail(e, DANI_ERR_INVALID, "bad class list");
+  SeqState* S = seq_state(e);
+  std::lock_guard<std::mutex> lk(S->mu);
+  S->class_names.assign(class_names, class_names + n_classes);
+  S->dynamic_names.assign(dynamic_names, dynamic_names + n_dynamic);
+  return DANI_OK;
+}
+
+int dani_frontend_reset(dani_engine* e, int32_t sequence) {
+  if (!e) return DANI_ERR_INVALID;
+  SeqState* S = seq_state(e, sequence);
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (S->ctx) S->ctx->prev_n = 0;
+  return DANI_OK;
+}
+
+int dani_frontend_timings(dani_engine* e, float* ms4) {
+  if (!e || !ms4 || !t_last_seq) return DANI_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    bool mine = false;
+    for (auto& kv : e->seqs) mine = mine || kv.second == t_last_seq;
+    if (!mine) return DANI_ERR_INVALID;
+  }
+  for (int i = 0; i < 4; i++) ms4[i] = t_last_seq->ms[i];
+  return DANI_OK;
+}
+
+int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, int32_t gray_stride, const uint8_t* bgr, int32_t bgr_stride,
+                        int32_t on_device, int32_t B, int32_t W, int32_t H, const dani_frontend_params* p, float* kpts_xy,
+                        float* resp, float* desc, int32_t cap, int32_t* n_out, int32_t* mono_index, int32_t* dyn_boxes,
+                        int32_t box_cap, int32_t* n_boxes, int32_t* matches, float* scores, int32_t match_cap,
+                        int32_t* k_out) {
+  if (!e || !p) return DANI_ERR_INVALID;
+  if (!gray || W <= 0 || H <= 0) return fail(e, DANI_ERR_EMPTY, "empty image");
+  if (B < 1 || B > e->cfg.max_batch) return fail(e, DANI_ERR_INVALID, "batch %d outside [1, %d]", B, e->cfg.max_batch);
+  if (p->use_yolo && (!bgr || !dyn_boxes || !n_boxes || box_cap < 1)) return fail(e, DANI_ERR_INVALID, "use_yolo needs bgr + box outputs");
+  if (p->match_previous && (!matches || !scores || !k_out || match_cap < 1)) return fail(e, DANI_ERR_INVALID, "match_previous needs match outputs");
+  SeqState* S0 = seq_state(e, 0);
+  SeqState* S = seq_state(e, sequence);
+  std::lock_guard<std::mutex> seq_lock(S->mu);
+  std::vector<std::string> class_names, dynamic_names;
+  if (p->use_yolo) {
+    if (S != S0) { std::lock_guard<std::mutex> lk0(S0->mu); class_names = S0->class_names; dynamic_names = S0->dynamic_names; }
+    else { class_names = S0->class_names; dynamic_names = S0->dynamic_names; }
+    if (class_names.empty()) return fail(e, DANI_ERR_INVALID, "call dani_yolo_set_classes first (coco.names)");
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (!S->ctx) {
+    Context* c = new Context();
+    HIP_TRY(e, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(e, create_priority_stream(&c->stream2));
+    (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
+    (void)hipEventCreate(&c->ev_lg0); (void)hipEventCreate(&c->ev_lg1);
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    for (auto& ev : c->lev) (void)hipEventCreate(&ev);
+    c->busy = true;   // never handed out by acquire()
+    { std::lock_guard<std::mutex> lk(e->mu); e->ctxs.push_back(c); }
+    S->ctx = c;
+  }
+  Context* c = S->ctx;
+  t_last_seq = S;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+
+  // ---- 0. enqueue the SuperPoint network first: it does not need the boxes, and running it on the main stream
+  //         while YOLO's ~70 small kernels run on the second stream fills the CUs those leave idle
+  std::vector<int32_t>& octave = S->octave;
+  std::vector<float>& size = S->size;
+  if (octave.size() < (size_t)B * cap) { octave.resize((size_t)B * cap); size.resize((size_t)B * cap); }
+  SpCall sp_call;
+  sp_call.ctx = c; sp_call.keep_desc_on_device = true; sp_call.phase = 1;
+  int rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
+                           octave.data(), size.data(), desc, cap, n_out, mono_index);
+  if (rc) return rc;
+
+  // ---- 1. YOLO -> dynamic boxes (Tracking.cc:1535-1539)
+  std::vector<int32_t> boxes, offs(B + 1, 0);
+  if (p->use_yolo) {
+    YoloCall yolo_call;
+    yolo_call.ctx = c; yolo_call.alt_stream = true;
+    const int dcap = 4096;
+    std::vector<float>& dets = S->dets;
+    std::vector<int32_t>& tmp = S->frame_boxes;            // per frame: up to dcap + 1 boxes
+    const size_t tstride = (size_t)(dcap + 1) * 4;
+    if (dets.size() < (size_t)B * dcap * 6) { dets.resize((size_t)B * dcap * 6); tmp.resize((size_t)B * tstride); }
+    std::vector<int32_t> nd(B);
+    std::vector<const char*> cn, dn;
+    for (auto& s : class_names) cn.push_back(s.c_str());
+    for (auto& s : dynamic_names) dn.push_back(s.c_str());
+    std::vector<int> kk(B, 0);
+    // box bookkeeping + RefineDynamicBoxes run in the same worker task as the frame's NMS
+    std::function<void(int, const float*, int)> areas = [&](int b, const float* d6, int n) {
+      kk[b] = yolo_dynamic_areas(d6, n, W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp.data() + (size_t)b * tstride, dcap + 1);
+    };
+    yolo_call.post = &areas;
+    rc = yolo_detect_impl(e, yolo_call, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
+    if (rc) return rc;
+    for (int b = 0; b < B; b++) {
+      const int k = kk[b];
+      n_boxes[b] = k;
+      if (k > box_cap) { return fail(e, DANI_ERR_CAPACITY, "frame %d has %d dynamic boxes (> %d)", b, k, box_cap); }
+      memcpy(dyn_boxes + (size_t)b * box_cap * 4, tmp.data() + (size_t)b * tstride, (size_t)k * 16);
+      boxes.insert(boxes.end(), tmp.begin() + (size_t)b * tstride, tmp.begin() + (size_t)b * tstride + (size_t)k * 4);
+      offs[b + 1] = offs[b] + k;
+    }
+  } else if (n_boxes) {
+    for (int b = 0; b < B; b++) n_boxes[b] = 0;
+  }
+  S->ms[0] = ms_since(t0);
+
+  // ---- 2. SuperPoint with the boxes as mvDynamicArea; descriptors stay resident for LightGlue
+  const auto t1 = std::chrono::steady_clock::now();
+  sp_call.phase = 2; sp_call.defer_desc_sync = true;
+  rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, boxes.empty() ? nullptr : boxes.data(),
+                       boxes.empty() ? nullptr : offs.data(), p->lapping, kpts_xy, resp, octave.data(), size.data(),
+                       desc, cap, n_out, mono_index);
+  if (rc) return rc;
+  S->ms[1] = ms_since(t1);
+
+  // ---- 3. LightGlue: frame b-1 (query) vs frame b (train); slot 0 of the feature slabs = previous call's last frame
+  const auto t2 = std::chrono::steady_clock::now();
+  // descriptor read-back: stream2 fills the pinned staging while LightGlue is being launched; the copy into the
+  // caller's array then runs on this thread under the forward pass
+  bool desc_moved = false;
+  bool cache_enqueued = false;
+  auto enqueue_cache = [&] {   // the last frame's features become the next call's predecessor (slot 0 of the slabs)
+    if (cache_enqueued) return;
+    cache_enqueued = true;
+    (void)hipMemcpyAsync(c->d_kxy_all, c->d_kxy + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream);
+  };
+  std::function<void()> move_desc = [&] {
+    enqueue_cache();           // behind the LightGlue kernels in stream order, ahead of the call's final synchronise
+    if (desc_moved || !desc) return;
+    desc_moved = true;
+    if (hipStreamSynchronize(c->stream2) != hipSuccess) return;
+    host_pool().run(B, [&](int b) {
+      if (n_out[b]) memcpy(desc + (size_t)b * cap * 256, c->h_desc + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024);
+    });
+  };
+  if (p->match_previous) {
+    std::vector<int32_t> n0(B), n1(B);
+    for (int b = 0; b < B; b++) { n0[b] = b ? n_out[b - 1] : c->prev_n; n1[b] = n_out[b]; }
+    const float sz[2] = {(float)W, (float)H};
+    LgCall lg_call;
+    lg_call.ctx = c; lg_call.overlap = &move_desc;
+    rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kxy_all, c->d_desc_all, n0.data(), c->d_kxy, c->d_descout, n1.data(), sz, sz,
+                             p->lg_threshold, matches, scores, match_cap, k_out);
+    if (rc) { move_desc(); (void)hipStreamSynchronize(c->stream); return rc; }
+  }
+  const bool synced = cache_enqueued;   // LightGlue ran: its final synchronise covered the cache copies
+  move_desc();
+  if (!synced) HIP_TRY(e, hipStreamSynchronize(c->stream));
+  HIP_TRY(e, hipStreamSynchronize(c->stream2));
+  HIP_TRY(e, hipGetLastError());
+  if (e->profiling) sp_read_timers(c, true);
+  c->prev_n = n_out[B - 1];
+  S->ms[2] = ms_since(t2);
+  S->ms[3] = ms_since(t0);
+  return DANI_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// descriptor-distance scans of the projection searches
+// ================================================================================================
+extern "C" int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt,
+                               const int32_t* t_level, const int32_t* cand_offsets, const int32_t* cand_idx,
+                               float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
+                               int32_t* best_level2) {
+  if (!e) return DANI_ERR_INVALID;
+  if (nq < 0 || nt < 0 || (nq && (!q_desc || !cand_offsets || !best_dist || !best_dist2 || !best_idx || !best_level || !best_level2)))
+    return fail(e, DANI_ERR_INVALID, "bad dani_desc_best2 argument");
+  if (nq == 0) return DANI_OK;
+  const int total = cand_offsets[nq];
+  if (total < 0 || (total && (!cand_idx || !t_desc))) return fail(e, DANI_ERR_INVALID, "bad candidate lists");
+  for (int i = 0; i < total; i++)
+    if (cand_idx[i] < 0 || cand_idx[i] >= nt) return fail(e, DANI_ERR_INVALID, "candidate index %d outside [0, %d)", cand_idx[i], nt);
+  HIP_TRY(e, hipSetDevice(e->device));
+  Context* c = acquire(e);
+  if (!c) return fail(e, DANI_ERR_INVALID, "all contexts busy");
+  struct Releaser { dani_engine* e; Context* c; ~Releaser() { release(e, c); } } rel{e, c};
+  hipStream_t s = c->stream;
+  const size_t bq = (size_t)nq * 1024, bt = (size_t)std::max(nt, 1) * 1024, bl = (size_t)std::max(nt, 1) * 4;
+  const size_t bo = (size_t)(nq + 1) * 4, bc = (size_t)std::max(total, 1) * 4, bout = (size_t)nq * 4;
+  const size_t need = bq + bt + bl + bo + bc + 5 * bout;
+  if (need > c->scan_ws_bytes) {   // grow-only: a tracking thread calls this every frame with similar sizes
+    if (c->scan_ws) (void)hipFree(c->scan_ws);
+    c->scan_ws = nullptr; c->scan_ws_bytes = 0;
+    HIP_TRY(e, hipMalloc((void**)&c->scan_ws, need + need / 4));
+    c->scan_ws_bytes = need + need / 4;
+  }
+  char* d = c->scan_ws;
+  float* dq = (float*)d; float* dt = (float*)(d + bq); int32_t* dl = (int32_t*)(d + bq + bt);
+  int32_t* doff = (int32_t*)(d + bq + bt + bl); int32_t* dci = (int32_t*)(d + bq + bt + bl + bo);
+  char* o = d + bq + bt + bl + bo + bc;
+  HIP_TRY(e, hipMemcpyAsync(dq, q_desc, bq, hipMemcpyHostToDevice, s));
+  if (nt) HIP_TRY(e, hipMemcpyAsync(dt, t_desc, (size_t)nt * 1024, hipMemcpyHostToDevice, s));
+  if (t_level && nt) HIP_TRY(e, hipMemcpyAsync(dl, t_level, (size_t)nt * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(e, hipMemcpyAsync(doff, cand_offsets, bo, hipMemcpyHostToDevice, s));
+  if (total) HIP_TRY(e, hipMemcpyAsync(dci, cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
+  launch_desc_best2(dq, dt, t_level ? dl : nullptr, doff, dci, nq, (float*)o, (float*)(o + bout), (int32_t*)(o + 2 * bout),
+                    (int32_t*)(o + 3 * bout), (int32_t*)(o + 4 * bout), s);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(best_dist, o, bout, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(best_dist2, o + bout, bout, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(best_idx, o + 2 * bout, bout, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(best_level, o + 3 * bout, bout, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(best_level2, o + 4 * bout, bout, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  return DANI_OK;
+}
+

@@ -1,0 +1,504 @@
+// lg_engine.cpp -- LightGlue part of the C ABI (weights packing/folding, workspaces, forward pass, match filter).
+#include "engine_internal.h"
+
+using namespace dani;
+using namespace dani::eng;
+
+// ================================================================================================
+// LightGlue
+// ================================================================================================
+namespace dani {
+namespace eng {
+
+constexpr int LG_LAYERS = 9;
+
+struct LgLinear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
+struct LgBlockW { LgLinear a, b, c, ffn0, ffn3; float* ln_g = nullptr; float* ln_b = nullptr; };  // self: a=Wqkv,b=out_proj; cross: a=to_qk,b=to_v,c=to_out
+struct LgWeights {
+  bool ready = false;
+  float* wr = nullptr;
+  LgBlockW self_[LG_LAYERS], cross_[LG_LAYERS];
+  LgLinear final_proj;
+  float* match_w = nullptr;
+  float match_b = 0.0f;
+};
+
+constexpr int LG_LINEARS = 6 * LG_LAYERS + 1;   // per layer: Wqkv, ffn.0, ffn.3 (self) + qk|v, ffn.0, ffn.3 (cross); final_proj
+struct LgContext {
+  int pairs = 0, kmax = 0, ld = 0, sim_ld = 0;
+  float *kpts = nullptr, *desc_tm = nullptr;  // token-major staging [ld][2], [ld][256]
+  LgSet* d_sets = nullptr;
+  float *x = nullptr, *qkv = nullptr, *ctx = nullptr, *msg = nullptr, *hbuf = nullptr, *qk = nullptr, *v = nullptr;
+  float *cosb = nullptr, *sinb = nullptr, *md = nullptr, *logsig = nullptr, *lse_row = nullptr, *lse_col = nullptr, *max0 = nullptr;
+  float *md_dense = nullptr, *logsig_dense = nullptr;   // assignment stage: sets contiguous (LgSet::dense_off)
+  int *m0 = nullptr, *m1 = nullptr;
+  float* sim = nullptr;
+  // pinned host
+  LgSet* h_sets = nullptr;
+  float* h_stage = nullptr;   // kpts + desc staging
+  int* h_m0 = nullptr; int* h_m1 = nullptr; float* h_max0 = nullptr;
+  std::vector<void*> dev_allocs, host_allocs;
+  int last_nsets = 0;
+  std::vector<LgSet> last_sets;
+  // profiling of the attention kernel (dominant kernel of the full front-end): events around its 18 launches
+  hipEvent_t aev[36] = {};
+  hipEvent_t lnev[2 * LG_LINEARS] = {};   // around every linear_fm launch of a forward pass
+  bool aev_ready = false;
+  float attn_ms = 0.0f, lin_ms = 0.0f;
+  double attn_flops = 0.0, lin_flops = 0.0;
+};
+
+
+LgWeights* lg_weights(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  if (!e->lgw) e->lgw = new LgWeights();
+  return e->lgw;
+}
+
+void lg_release(dani_engine* e) {
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (Context* c : e->ctxs) {
+    LgContext* L = c->lg;
+    if (!L) continue;
+    for (void* p : L->dev_allocs) (void)hipFree(p);
+    for (void* p : L->host_allocs) (void)hipHostFree(p);
+    if (L->aev_ready) { for (auto& ev : L->aev) (void)hipEventDestroy(ev); for (auto& ev : L->lnev) (void)hipEventDestroy(ev); }
+    delete L;
+    c->lg = nullptr;
+  }
+  delete e->lgw;   // device weights are in e->weight_allocs
+  e->lgw = nullptr;
+}
+
+int lg_upload(dani_engine* e, const std::vector<float>& v, float** out) {
+  HIP_TRY(e, hipMalloc((void**)out, v.size() * 4));
+  e->weight_allocs.push_back(*out);
+  HIP_TRY(e, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+// pack a Linear ([out, in] row-major + bias) for linear_fm_kernel
+int lg_pack_raw(dani_engine* e, const std::vector<float>& w, const std::vector<float>& b, int out, int in, LgLinear* L) {
+  const int tiles = (out + 63) / 64;
+  std::vector<float> wp((size_t)tiles * 64 * in), bp((size_t)tiles * 64);
+  pack_conv_weights(w.data(), b.data(), in, out, 1, 32, 64, wp.data(), bp.data());
+  L->out = out; L->in = in;
+  int rc;
+  if ((rc = lg_upload(e, wp, &L->w))) return rc;
+  return lg_upload(e, bp, &L->b);
+}
+
+int lg_get_linear(dani_engine* e, const std::string& name, int out, int in, std::vector<float>& w, std::vector<float>& b) {
+  auto wi = e->tensors.find(name + ".weight"), bi = e->tensors.find(name + ".bias");
+  if (wi == e->tensors.end() || bi == e->tensors.end()) return fail(e, DANI_ERR_WEIGHTS, "missing tensor %s.weight/.bias", name.c_str());
+  if (wi->second.size() != (size_t)out * in || bi->second.size() != (size_t)out)
+    return fail(e, DANI_ERR_WEIGHTS, "tensor %s.weight has %zu floats, expected [%d,%d]", name.c_str(), wi->second.size(), out, in);
+  w = wi->second; b = bi->second;
+  return 0;
+}
+
+int lg_pack_linear(dani_engine* e, const std::string& name, int out, int in, LgLinear* L, const std::vector<int>* perm = nullptr) {
+  std::vector<float> w, b;
+  int rc = lg_get_linear(e, name, out, in, w, b);
+  if (rc) return rc;
+  if (perm) {
+    std::vector<float> w2(w.size()), b2(b.size());
+    for (int r = 0; r < out; r++) {
+      memcpy(&w2[(size_t)r * in], &w[(size_t)(*perm)[r] * in], (size_t)in * 4);
+      b2[r] = b[(*perm)[r]];
+    }
+    w.swap(w2); b.swap(b2);
+  }
+  return lg_pack_raw(e, w, b, out, in, L);
+}
+
+// ffn.0 applied to cat[x, P(ctx)] with P an affine map (out_proj / to_out) folded in:
+//   W0 [x ; Wp ctx + bp] + b0 = [W0a | W0b Wp] [x ; ctx] + (b0 + W0b bp)        (products accumulated in double)
+// This removes one 256x256 GEMM launch per block (18 per forward) without changing the function computed.
+int lg_pack_ffn0_folded(dani_engine* e, const std::string& ffn0, const std::string& proj, LgLinear* L) {
+  std::vector<float> w0, b0, wp, bp;
+  int rc;
+  if ((rc = lg_get_linear(e, ffn0, 512, 512, w0, b0))) return rc;
+  if ((rc = lg_get_linear(e, proj, 256, 256, wp, bp))) return rc;
+  std::vector<float> w(w0), b(b0);
+  for (int o = 0; o < 512; o++) {
+    const float* w0b = &w0[(size_t)o * 512 + 256];
+    for (int k = 0; k < 256; k++) {
+      double acc = 0.0;
+      for (int m = 0; m < 256; m++) acc += (double)w0b[m] * (double)wp[(size_t)m * 256 + k];
+      w[(size_t)o * 512 + 256 + k] = (float)acc;
+    }
+    double bb = (double)b0[o];
+    for (int m = 0; m < 256; m++) bb += (double)w0b[m] * (double)bp[m];
+    b[o] = (float)bb;
+  }
+  return lg_pack_raw(e, w, b, 512, 512, L);
+}
+
+// to_qk (pre-scaled by 64^-1/4, the factor the public CrossBlock applies to both sides) and to_v as one 512-row GEMM
+int lg_pack_qkv_cross(dani_engine* e, const std::string& pc, LgLinear* L) {
+  std::vector<float> wq, bq, wv, bv;
+  int rc;
+  if ((rc = lg_get_linear(e, pc + ".to_qk", 256, 256, wq, bq))) return rc;
+  if ((rc = lg_get_linear(e, pc + ".to_v", 256, 256, wv, bv))) return rc;
+  const float sc = 0.35355339059327373f;
+  std::vector<float> w((size_t)512 * 256), b(512);
+  for (size_t i = 0; i < wq.size(); i++) w[i] = wq[i] * sc;
+  for (int i = 0; i < 256; i++) b[i] = bq[i] * sc;
+  memcpy(&w[(size_t)256 * 256], wv.data(), wv.size() * 4);
+  memcpy(&b[256], bv.data(), 256 * 4);
+  return lg_pack_raw(e, w, b, 512, 256, L);
+}
+
+int lg_vec(dani_engine* e, const std::string& name, size_t n, float** out) {
+  auto it = e->tensors.find(name);
+  if (it == e->tensors.end() || it->second.size() != n) return fail(e, DANI_ERR_WEIGHTS, "missing or mis-shaped tensor %s", name.c_str());
+  return lg_upload(e, it->second, out);
+}
+
+int lg_finalize(dani_engine* e) {
+  LgWeights* W = lg_weights(e);
+  W->ready = false;
+  if (e->tensors.find("posenc.Wr.weight") == e->tensors.end()) return 0;  // LightGlue weights not supplied: SP-only engine
+  int rc;
+  if ((rc = lg_vec(e, "posenc.Wr.weight", 64, &W->wr))) return rc;
+  // Wqkv rows: reference order h*192 + d*3 + {q,k,v}  ->  kernel order {q,k,v}*256 + h*64 + d
+  std::vector<int> perm(768);
+  for (int which = 0; which < 3; which++)
+    for (int h = 0; h < 4; h++)
+      for (int d = 0; d < 64; d++) perm[which * 256 + h * 64 + d] = h * 192 + d * 3 + which;
+  for (int i = 0; i < LG_LAYERS; i++) {
+    const std::string ps = "transformers." + std::to_string(i) + ".self_attn", pc = "transformers." + std::to_string(i) + ".cross_attn";
+    LgBlockW& S = W->self_[i]; LgBlockW& C = W->cross_[i];
+    if ((rc = lg_pack_linear(e, ps + ".Wqkv", 768, 256, &S.a, &perm))) return rc;
+    if ((rc = lg_pack_ffn0_folded(e, ps + ".ffn.0", ps + ".out_proj", &S.ffn0))) return rc;
+    if ((rc = lg_vec(e, ps + ".ffn.1.weight", 512, &S.ln_g))) return rc;
+    if ((rc = lg_vec(e, ps + ".ffn.1.bias", 512, &S.ln_b))) return rc;
+    if ((rc = lg_pack_linear(e, ps + ".ffn.3", 256, 512, &S.ffn3))) return rc;
+    if ((rc = lg_pack_qkv_cross(e, pc, &C.a))) return rc;
+    if ((rc = lg_pack_ffn0_folded(e, pc + ".ffn.0", pc + ".to_out", &C.ffn0))) return rc;
+    if ((rc = lg_vec(e, pc + ".ffn.1.weight", 512, &C.ln_g))) return rc;
+    if ((rc = lg_vec(e, pc + ".ffn.1.bias", 512, &C.ln_b))) return rc;
+    if ((rc = lg_pack_linear(e, pc + ".ffn.3", 256, 512, &C.ffn3))) return rc;
+  }
+  const std::string pa = "log_assignment." + std::to_string(LG_LAYERS - 1);
+  if ((rc = lg_pack_linear(e, pa + ".final_proj", 256, 256, &W->final_proj))) return rc;
+  if ((rc = lg_vec(e, pa + ".matchability.weight", 256, &W->match_w))) return rc;
+  auto mb = e->tensors.find(pa + ".matchability.bias");
+  if (mb == e->tensors.end() || mb->second.size() != 1) return fail(e, DANI_ERR_WEIGHTS, "missing %s.matchability.bias", pa.c_str());
+  W->match_b = mb->second[0];
+  W->ready = true;
+  return 0;
+}
+
+int lg_dev(dani_engine* e, LgContext* L, void** p, size_t bytes) {
+  HIP_TRY(e, hipMalloc(p, bytes));
+  L->dev_allocs.push_back(*p);
+  HIP_TRY(e, hipMemset(*p, 0, bytes));
+  return 0;
+}
+int lg_host(dani_engine* e, LgContext* L, void** p, size_t bytes) {
+  HIP_TRY(e, hipHostMalloc(p, bytes, hipHostMallocDefault));
+  L->host_allocs.push_back(*p);
+  return 0;
+}
+
+int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) {
+  LgContext* L;
+  {
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!c->lg) c->lg = new LgContext();
+    L = c->lg;
+  }
+  *out = L;
+  if (L->pairs >= pairs && L->kmax >= kmax) return 0;
+  for (void* p : L->dev_allocs) (void)hipFree(p);
+  for (void* p : L->host_allocs) (void)hipHostFree(p);
+  L->dev_allocs.clear(); L->host_allocs.clear();
+  pairs = std::max(pairs, L->pairs); kmax = std::max(kmax, L->kmax);
+  const int np = round_up(kmax, 32);
+  const int ld = round_up(pairs * 2 * np + round_up(pairs * 2 * LG_TAIL_MAX, 32) + 128, 256);   // main regions + shared tail region
+  int rc;
+#define LGA(ptr, rows) if ((rc = lg_dev(e, L, (void**)&(ptr), (size_t)(rows) * ld * 4))) return rc;
+  LGA(L->x, 256) LGA(L->qkv, 768) LGA(L->ctx, 256) LGA(L->msg, 256) LGA(L->hbuf, 512) LGA(L->qk, 256) LGA(L->v, 256)
+  LGA(L->cosb, 32) LGA(L->sinb, 32) LGA(L->md, 256) LGA(L->logsig, 1) LGA(L->lse_row, 1) LGA(L->lse_col, 1) LGA(L->md_dense, 256) LGA(L->logsig_dense, 1)
+  LGA(L->m0, 3) LGA(L->kpts, 2) LGA(L->desc_tm, 256)   // m0 | m1 | max0 are rows of one block: one read-back
+  L->m1 = L->m0 + ld; L->max0 = reinterpret_cast<float*>(L->m0 + 2 * (size_t)ld);
+#undef LGA
+  L->sim_ld = round_up(np + 128, 64);
+  if ((rc = lg_dev(e, L, (void**)&L->sim, (size_t)pairs * (np + 64) * L->sim_ld * 4))) return rc;
+  if ((rc = lg_dev(e, L, (void**)&L->d_sets, sizeof(LgSet) * 2 * pairs))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_sets, sizeof(LgSet) * 2 * pairs))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_stage, (size_t)ld * 258 * 4))) return rc;
+  if ((rc = lg_host(e, L, (void**)&L->h_m0, (size_t)ld * 12))) return rc;
+  L->h_m1 = L->h_m0 + ld; L->h_max0 = reinterpret_cast<float*>(L->h_m0 + 2 * (size_t)ld);
+  HIP_TRY(e, hipDeviceSynchronize());   // null-stream zero fills vs the engine's non-blocking streams
+  L->pairs = pairs; L->kmax = kmax; L->ld = ld;
+  return 0;
+}
+
+// the 9-layer forward + assignment statistics on stream s; the sets in L->d_sets point at their token-major inputs
+struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T; };   // T = all main regions + the tail region
+
+void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof) {
+  const int ld = L->ld, nsets = sh.nsets, max_n = sh.max_n, T = sh.T, max_np = round_up(max_n, 32);
+  if (prof && !L->aev_ready) {
+    for (auto& ev : L->aev) (void)hipEventCreate(&ev);
+    for (auto& ev : L->lnev) (void)hipEventCreate(&ev);
+    L->aev_ready = true;
+  }
+  int ai = 0, li = 0;
+  auto attn = [&](const float* Q, const float* K, const float* V, int cross, float scale) {
+    if (prof) (void)hipEventRecord(L->aev[ai++], s);
+    launch_attention(Q, K, V, L->ctx, ld, L->d_sets, nsets, sh.max_mp, sh.max_tail, cross, scale, s);
+    if (prof) (void)hipEventRecord(L->aev[ai++], s);
+  };
+  launch_desc_to_fm(L->d_sets, nsets, sh.max_span, L->x, ld, s);
+  launch_posenc(L->d_sets, nsets, sh.max_span, W->wr, L->cosb, L->sinb, ld, s);
+  auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
+    if (prof) (void)hipEventRecord(L->lnev[li++], s);
+    launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
+    if (prof) (void)hipEventRecord(L->lnev[li++], s);
+  };
+  for (int i = 0; i < LG_LAYERS; i++) {
+    const LgBlockW& S = W->self_[i]; const LgBlockW& C = W->cross_[i];
+    // self block: Wqkv (+rotary) -> attention -> [out_proj folded into] ffn.0 -> LN+GELU -> ffn.3 + residual
+    lin(S.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 512, 1.0f);
+    attn(L->qkv, L->qkv + (size_t)256 * ld, L->qkv + (size_t)512 * ld, 0, 0.125f);
+    lin(S.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
+    launch_ln_gelu(L->hbuf, S.ln_g, S.ln_b, T, ld, s);
+    lin(S.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
+    // cross block: [to_qk*s | to_v] in one GEMM -> attention over the partner set -> [to_out folded into] ffn.0 ...
+    lin(C.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 0, 1.0f);
+    attn(L->qkv, L->qkv, L->qkv + (size_t)256 * ld, 1, 1.0f);
+    lin(C.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
+    launch_ln_gelu(L->hbuf, C.ln_g, C.ln_b, T, ld, s);
+    lin(C.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
+  }
+  lin(W->final_proj, L->x, 256, nullptr, 0, L->md, nullptr, 0, 0.25f);   // / d^0.25, d = 256
+  launch_matchability(L->x, W->match_w, W->match_b, L->logsig, T, ld, s);
+  const size_t pstride = (size_t)(round_up(L->kmax, 32) + 64) * L->sim_ld;
+  launch_lg_densify(L->md, L->logsig, L->d_sets, nsets, max_n, L->md_dense, L->logsig_dense, ld, s);
+  launch_sim(L->md_dense, ld, L->d_sets, nsets / 2, max_np, L->sim, L->sim_ld, pstride, s);
+  launch_assignment_stats(L->sim, L->sim_ld, pstride, L->d_sets, nsets / 2, max_n, L->logsig_dense, L->lse_row, L->lse_col,
+                          L->m0, L->max0, L->m1, ld, s);
+}
+
+thread_local LgContext* t_last_lg = nullptr;
+LgContext* last_lg(dani_engine* e) {
+  if (!e || !t_last_lg) return nullptr;
+  std::lock_guard<std::mutex> lk(e->mu);
+  for (Context* c : e->ctxs) if (c->lg && c->lg == t_last_lg) return t_last_lg;
+  return nullptr;
+}
+
+}  // namespace eng
+}  // namespace dani
+
+extern "C" {
+
+}  // extern "C"
+
+namespace dani {
+namespace eng {
+
+int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap, int32_t on_device, const float* kpts0,
+                  const float* desc0, const int32_t* n0, const float* kpts1, const float* desc1, const int32_t* n1,
+                  const float* size0, const float* size1, float threshold, int32_t* matches, float* scores,
+                  int32_t cap, int32_t* k_out) {
+  if (!e) return DANI_ERR_INVALID;
+  if (P < 1 || !n0 || !n1 || !kpts0 || !kpts1 || !desc0 || !desc1 || !matches || !scores || !k_out || cap < 1 || in_cap < 1)
+    return fail(e, DANI_ERR_INVALID, "bad dani_lg_match argument");
+  LgWeights* W = lg_weights(e);
+  if (!e->finalized || !W->ready) return fail(e, DANI_ERR_WEIGHTS, "LightGlue weights not loaded/finalized");
+  int kmax = 1;
+  for (int p = 0; p < P; p++) {
+    if (n0[p] < 0 || n1[p] < 0 || n0[p] > in_cap || n1[p] > in_cap) return fail(e, DANI_ERR_INVALID, "pair %d: bad keypoint count", p);
+    kmax = std::max(kmax, std::max(n0[p], n1[p]));
+  }
+  HIP_TRY(e, hipSetDevice(e->device));
+  CtxLease lease(e, call.ctx);
+  Context* c = lease.c;
+  if (!c) return fail(e, DANI_ERR_INVALID, "all contexts busy");
+  LgContext* L = nullptr;
+  int rc = lg_ensure(e, c, &L, P, kmax);
+  if (rc) return rc;
+  t_last_lg = L;
+  hipStream_t s = c->stream;
+  // token layout (common.h, LgSet): set 2p = side 0 of pair p, set 2p+1 = side 1.  Main regions first, each padded to a
+  // multiple of 32 tokens; then the shared tail region; the dense layout of the assignment stage pads every set to 32.
+  int off = 0, doff = 0, ntail = 0, max_n = 0;
+  LgShape sh{2 * P, 0, 0, 0, 0, 0};
+  L->last_sets.assign(2 * P, LgSet());
+  auto place = [&](LgSet& a, int n) {
+    const int t = n % 32;
+    a.n = n; a.nmain = (n >= 32 && t > 0 && t <= LG_TAIL_MAX) ? n - t : n;
+    a.tok_off = off; off += round_up(std::max(a.nmain, 1), 32);
+    a.dense_off = doff; doff += round_up(std::max(n, 1), 32);
+    a.tail_off = ntail; ntail += n - a.nmain;            // relative to the tail region for now
+    max_n = std::max(max_n, n);
+    sh.max_mp = std::max(sh.max_mp, round_up(a.nmain, 32));
+    sh.max_span = std::max(sh.max_span, round_up(a.nmain, 32) + (n - a.nmain));
+    sh.max_tail = std::max(sh.max_tail, n - a.nmain);
+  };
+  for (int p = 0; p < P; p++) { place(L->last_sets[2 * p], n0[p]); place(L->last_sets[2 * p + 1], n1[p]); }
+  const int T_main = off;
+  for (LgSet& a : L->last_sets) a.tail_off += T_main;
+  for (int p = 0; p < P; p++) {
+    LgSet& a = L->last_sets[2 * p]; LgSet& b = L->last_sets[2 * p + 1];
+    a.partner_off = b.tok_off; a.partner_n = b.n; a.partner_nmain = b.nmain; a.partner_tail_off = b.tail_off;
+    b.partner_off = a.tok_off; b.partner_n = a.n; b.partner_nmain = a.nmain; b.partner_tail_off = a.tail_off;
+  }
+  const int T = T_main + round_up(ntail, 32);
+  sh.max_n = max_n; sh.T = T;
+  // sizes: explicit (w,h) or 1 + max - min of the keypoints (needs host keypoints)
+  std::vector<float> hk;
+  auto host_kpts = [&](const float* k, int p, int n) -> const float* {
+    if (!on_device) return k + (size_t)p * in_cap * 2;
+    hk.resize((size_t)n * 2);
+    (void)hipMemcpy(hk.data(), k + (size_t)p * in_cap * 2, (size_t)n * 8, hipMemcpyDeviceToHost);
+    return hk.data();
+  };
+  for (int p = 0; p < P; p++)
+    for (int side = 0; side < 2; side++) {
+      LgSet& st = L->last_sets[2 * p + side];
+      const float* sz = side ? size1 : size0;
+      if (sz) { st.size_w = sz[0]; st.size_h = sz[1]; }
+      else {
+        const float* k = host_kpts(side ? kpts1 : kpts0, p, st.n);
+        float mnx = 3e38f, mny = 3e38f, mxx = -3e38f, mxy = -3e38f;
+        for (int i = 0; i < st.n; i++) { mnx = std::min(mnx, k[2 * i]); mxx = std::max(mxx, k[2 * i]); mny = std::min(mny, k[2 * i + 1]); mxy = std::max(mxy, k[2 * i + 1]); }
+        st.size_w = st.n ? 1.0f + (mxx - mnx) : 1.0f; st.size_h = st.n ? 1.0f + (mxy - mny) : 1.0f;
+      }
+    }
+  // inputs: device-resident sets are read in place; host sets go through ONE pinned staging block and two copies
+  for (int p = 0; p < P; p++)
+    for (int side = 0; side < 2; side++) {
+      LgSet& st = L->last_sets[2 * p + side];
+      const float* k = (side ? kpts1 : kpts0) + (size_t)p * in_cap * 2;
+      const float* d = (side ? desc1 : desc0) + (size_t)p * in_cap * 256;
+      if (on_device) { st.kp = k; st.desc = d; continue; }
+      st.kp = L->kpts + (size_t)st.dense_off * 2; st.desc = L->desc_tm + (size_t)st.dense_off * 256;
+      memcpy(L->h_stage + (size_t)st.dense_off * 2, k, (size_t)st.n * 8);
+      memcpy(L->h_stage + (size_t)L->ld * 2 + (size_t)st.dense_off * 256, d, (size_t)st.n * 1024);
+    }
+  if (!on_device && doff > 0) {
+    HIP_TRY(e, hipMemcpyAsync(L->kpts, L->h_stage, (size_t)doff * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(L->desc_tm, L->h_stage + (size_t)L->ld * 2, (size_t)doff * 1024, hipMemcpyHostToDevice, s));
+  }
+  // padding columns of the tail region: keep the residual stream finite there (they are never read as keys)
+  if (T > T_main + ntail)
+    HIP_TRY(e, hipMemset2DAsync(L->x + T_main + ntail, (size_t)L->ld * 4, 0, (size_t)(T - T_main - ntail) * 4, 256, s));
+  memcpy(L->h_sets, L->last_sets.data(), sizeof(LgSet) * 2 * P);
+  HIP_TRY(e, hipMemcpyAsync(L->d_sets, L->h_sets, sizeof(LgSet) * 2 * P, hipMemcpyHostToDevice, s));
+  HIP_TRY(e, hipEventRecord(c->ev_lg0, s));
+  const bool prof = e->profiling;
+  if (max_n > 0) lg_forward(W, L, sh, s, prof);
+  HIP_TRY(e, hipEventRecord(c->ev_lg1, s));
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpy2DAsync(L->h_m0, (size_t)L->ld * 4, L->m0, (size_t)L->ld * 4, (size_t)doff * 4, 3, hipMemcpyDeviceToHost, s));
+  if (call.overlap) (*call.overlap)();   // host work of the caller that can run under the forward pass
+  HIP_TRY(e, hipStreamSynchronize(s));
+  (void)hipEventElapsedTime(&c->ms[0], c->ev_lg0, c->ev_lg1);
+  c->ms[4] = c->ms[0];
+  t_last_ctx = c;
+  if (prof && max_n > 0) {
+    float tot = 0.0f;
+    for (int i = 0; i < 36; i += 2) { float m = 0.0f; (void)hipEventElapsedTime(&m, L->aev[i], L->aev[i + 1]); tot += m; }
+    L->attn_ms = tot;
+    double fl = 0.0;   // algorithmic: per launch, per set: 4 heads x (QK^T + PV) = 2 * 2 * nq * nk * 256 flop
+    for (const LgSet& st : L->last_sets) fl += 9.0 * 4.0 * 256.0 * st.n * ((double)st.n + (double)st.partner_n);
+    L->attn_flops = fl;
+    tot = 0.0f;
+    for (int i = 0; i < 2 * LG_LINEARS; i += 2) { float m = 0.0f; (void)hipEventElapsedTime(&m, L->lnev[i], L->lnev[i + 1]); tot += m; }
+    L->lin_ms = tot;
+    double ntok = 0.0;   // algorithmic: valid tokens only; per token 2 * out * in flop per layer
+    for (const LgSet& st : L->last_sets) ntok += st.n;
+    L->lin_flops = ntok * 2.0 * (LG_LAYERS * (768.0 * 256 + 512.0 * 256 + 2 * (512.0 * 512 + 256.0 * 512)) + 256.0 * 256);
+  }
+  // mutual check + thresholds (filter_matches of the model at 0.1, then LightGlue::filterMatches, src/LightGlue.cpp:98-122)
+  int status = DANI_OK;
+  for (int p = 0; p < P; p++) {
+    const LgSet& a = L->last_sets[2 * p]; const LgSet& b = L->last_sets[2 * p + 1];
+    int k = 0;
+    int32_t* mo = matches + (size_t)p * cap * 2;
+    float* so = scores + (size_t)p * cap;
+    if (a.n > 0 && b.n > 0)
+      for (int i = 0; i < a.n; i++) {
+        const int jj = L->h_m0[a.dense_off + i];
+        if (jj < 0 || jj >= b.n || L->h_m1[b.dense_off + jj] != i) continue;
+        const float ms = std::exp(L->h_max0[a.dense_off + i]);
+        if (!(ms > 0.1f) || !(ms > threshold)) continue;
+        if (k < cap) { mo[2 * k] = i; mo[2 * k + 1] = jj; so[k] = ms; }
+        k++;
+      }
+    k_out[p] = k;
+    if (k > cap) status = DANI_ERR_CAPACITY;
+  }
+  if (status != DANI_OK) return fail(e, status, "match capacity %d too small", cap);
+  return DANI_OK;
+}
+
+}  // namespace eng
+}  // namespace dani
+
+extern "C" {
+
+int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int32_t on_device, const float* kpts0,
+                        const float* desc0, const int32_t* n0, const float* kpts1, const float* desc1, const int32_t* n1,
+                        const float* size0, const float* size1, float threshold, int32_t* matches, float* scores,
+                        int32_t cap, int32_t* k_out) {
+  return lg_match_impl(e, LgCall{}, P, in_cap, on_device, kpts0, desc0, n0, kpts1, desc1, n1, size0, size1, threshold, matches, scores,
+                       cap, k_out);
+}
+
+int dani_lg_match(dani_engine* e, const float* kpts0, const float* desc0, int32_t n0, const float* kpts1,
+                  const float* desc1, int32_t n1, const float* size0, const float* size1, float threshold,
+                  int32_t* matches, float* scores, int32_t cap, int32_t* k_out) {
+  if (n0 == 0 || n1 == 0) { if (k_out) *k_out = 0; return e ? DANI_OK : DANI_ERR_INVALID; }
+  const int in_cap = std::max(n0, n1);
+  return dani_lg_match_batch(e, 1, in_cap, 0, kpts0, desc0, &n0, kpts1, desc1, &n1, size0, size1, threshold, matches,
+                             scores, cap, k_out);
+}
+
+int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches) {
+  LgContext* L = last_lg(e);
+  if (!e || !L) return DANI_ERR_INVALID;
+  if (total_ms) *total_ms = L->attn_ms;
+  if (total_flop) *total_flop = L->attn_flops;
+  if (launches) *launches = 18;
+  return DANI_OK;
+}
+
+int dani_lg_linear_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches) {
+  LgContext* L = last_lg(e);
+  if (!e || !L) return DANI_ERR_INVALID;
+  if (total_ms) *total_ms = L->lin_ms;
+  if (total_flop) *total_flop = L->lin_flops;
+  if (launches) *launches = LG_LINEARS;
+  return DANI_OK;
+}
+
+int dani_lg_debug_fetch(dani_engine* e, int32_t set, float* desc_out, int32_t* m0, float* max0, int32_t cap) {
+  LgContext* L = last_lg(e);
+  if (!e || !L || set < 0 || set >= (int)L->last_sets.size()) return fail(e, DANI_ERR_INVALID, "no previous LightGlue call on this thread");
+  const LgSet& st = L->last_sets[set];
+  if (st.n > cap) return fail(e, DANI_ERR_CAPACITY, "need %d", st.n);
+  HIP_TRY(e, hipSetDevice(e->device));
+  if (desc_out) {
+    std::vector<float> tmp((size_t)256 * st.n);
+    for (int f = 0; f < 256; f++) {
+      HIP_TRY(e, hipMemcpy(&tmp[(size_t)f * st.n], L->x + (size_t)f * L->ld + st.tok_off, (size_t)st.nmain * 4, hipMemcpyDeviceToHost));
+      if (st.n > st.nmain)
+        HIP_TRY(e, hipMemcpy(&tmp[(size_t)f * st.n + st.nmain], L->x + (size_t)f * L->ld + st.tail_off, (size_t)(st.n - st.nmain) * 4, hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < st.n; i++)
+      for (int f = 0; f < 256; f++) desc_out[(size_t)i * 256 + f] = tmp[(size_t)f * st.n + i];
+  }
+  if (m0) memcpy(m0, L->h_m0 + st.dense_off, (size_t)st.n * 4);
+  if (max0) memcpy(max0, L->h_max0 + st.dense_off, (size_t)st.n * 4);
+  return DANI_OK;
+}
+
+}  // extern "C"
+
