@@ -120,7 +120,7 @@ void launch_copy_layer_dense(const ActDesc& a, int b, float* out_dense, hipStrea
 // L2 descriptor distance + best / second-best scan over candidate lists (CSR)
 void launch_desc_best2(const float* q, const float* t, const int32_t* t_level, const int32_t* cand_off,
                        const int32_t* cand_idx, int nq, float* best_dist, float* best_dist2, int32_t* best_idx,
-                       int32_t* best_level, int32_t* best_level2, hipStream_t s);
+                       int32_t* best_level, int32_t* best_level2, float* cand_dist, hipStream_t s);
 
 // ---- LightGlue kernels (lg_kernels.hip) ------------------------------------------------------------
 // One keypoint set of a LightGlue batch.  Token layout of the transformer stage (all activations [features][ld]):

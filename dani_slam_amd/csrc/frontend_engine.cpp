@@ -211,10 +211,11 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
 // ================================================================================================
 // descriptor-distance scans of the projection searches
 // ================================================================================================
-extern "C" int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt,
-                               const int32_t* t_level, const int32_t* cand_offsets, const int32_t* cand_idx,
-                               float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
-                               int32_t* best_level2) {
+namespace {
+
+int desc_scan(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt, const int32_t* t_level,
+              const int32_t* cand_offsets, const int32_t* cand_idx, float* best_dist, float* best_dist2, int32_t* best_idx,
+              int32_t* best_level, int32_t* best_level2, float* cand_dist) {
   if (!e) return DANI_ERR_INVALID;
   if (nq < 0 || nt < 0 || (nq && (!q_desc || !cand_offsets || !best_dist || !best_dist2 || !best_idx || !best_level || !best_level2)))
     return fail(e, DANI_ERR_INVALID, "bad dani_desc_best2 argument");
@@ -230,7 +231,7 @@ extern "C" int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, 
   hipStream_t s = c->stream;
   const size_t bq = (size_t)nq * 1024, bt = (size_t)std::max(nt, 1) * 1024, bl = (size_t)std::max(nt, 1) * 4;
   const size_t bo = (size_t)(nq + 1) * 4, bc = (size_t)std::max(total, 1) * 4, bout = (size_t)nq * 4;
-  const size_t need = bq + bt + bl + bo + bc + 5 * bout;
+  const size_t need = bq + bt + bl + bo + 2 * bc + 5 * bout;   // ... + per-candidate distances
   if (need > c->scan_ws_bytes) {   // grow-only: a tracking thread calls this every frame with similar sizes
     if (c->scan_ws) (void)hipFree(c->scan_ws);
     c->scan_ws = nullptr; c->scan_ws_bytes = 0;
@@ -241,20 +242,44 @@ extern "C" int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, 
   float* dq = (float*)d; float* dt = (float*)(d + bq); int32_t* dl = (int32_t*)(d + bq + bt);
   int32_t* doff = (int32_t*)(d + bq + bt + bl); int32_t* dci = (int32_t*)(d + bq + bt + bl + bo);
   char* o = d + bq + bt + bl + bo + bc;
+  float* dcd = (float*)(o + 5 * bout);
   HIP_TRY(e, hipMemcpyAsync(dq, q_desc, bq, hipMemcpyHostToDevice, s));
   if (nt) HIP_TRY(e, hipMemcpyAsync(dt, t_desc, (size_t)nt * 1024, hipMemcpyHostToDevice, s));
   if (t_level && nt) HIP_TRY(e, hipMemcpyAsync(dl, t_level, (size_t)nt * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(e, hipMemcpyAsync(doff, cand_offsets, bo, hipMemcpyHostToDevice, s));
   if (total) HIP_TRY(e, hipMemcpyAsync(dci, cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
   launch_desc_best2(dq, dt, t_level ? dl : nullptr, doff, dci, nq, (float*)o, (float*)(o + bout), (int32_t*)(o + 2 * bout),
-                    (int32_t*)(o + 3 * bout), (int32_t*)(o + 4 * bout), s);
+                    (int32_t*)(o + 3 * bout), (int32_t*)(o + 4 * bout), cand_dist ? dcd : nullptr, s);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemcpyAsync(best_dist, o, bout, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipMemcpyAsync(best_dist2, o + bout, bout, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipMemcpyAsync(best_idx, o + 2 * bout, bout, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipMemcpyAsync(best_level, o + 3 * bout, bout, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipMemcpyAsync(best_level2, o + 4 * bout, bout, hipMemcpyDeviceToHost, s));
+  if (cand_dist && total) HIP_TRY(e, hipMemcpyAsync(cand_dist, dcd, (size_t)total * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipStreamSynchronize(s));
   return DANI_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt,
+                    const int32_t* t_level, const int32_t* cand_offsets, const int32_t* cand_idx,
+                    float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
+                    int32_t* best_level2) {
+  return desc_scan(e, q_desc, nq, t_desc, nt, t_level, cand_offsets, cand_idx, best_dist, best_dist2, best_idx, best_level,
+                   best_level2, nullptr);
+}
+
+int dani_desc_scan(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt,
+                   const int32_t* t_level, const int32_t* cand_offsets, const int32_t* cand_idx,
+                   float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
+                   int32_t* best_level2, float* cand_dist) {
+  if (!cand_dist && nq > 0 && cand_offsets && cand_offsets[nq] > 0) return fail(e, DANI_ERR_INVALID, "dani_desc_scan needs cand_dist");
+  return desc_scan(e, q_desc, nq, t_desc, nt, t_level, cand_offsets, cand_idx, best_dist, best_dist2, best_idx, best_level,
+                   best_level2, cand_dist);
+}
+
+}  // extern "C"

@@ -407,7 +407,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __global__ __launch_bounds__(64) void desc_best2_kernel(const float* q, const float* t, const int32_t* t_level,
                                                         const int32_t* cand_off, const int32_t* cand_idx, int nq,
                                                         float* best_dist, float* best_dist2, int32_t* best_idx,
-                                                        int32_t* best_level, int32_t* best_level2) {
+                                                        int32_t* best_level, int32_t* best_level2, float* cand_dist) {
   const int qi = blockIdx.x, lane = threadIdx.x;
   if (qi >= nq) return;
   const float4 a = reinterpret_cast<const float4*>(q + (size_t)qi * 256)[lane];
@@ -419,8 +419,9 @@ __global__ __launch_bounds__(64) void desc_best2_kernel(const float* q, const fl
     const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
     return (double)d0 * (double)d0 + (double)d1 * (double)d1 + (double)d2 * (double)d2 + (double)d3 * (double)d3;
   };
-  auto visit = [&](double ssum, int idx) {
+  auto visit = [&](double ssum, int idx, int c_) {
     const float dist = (float)sqrt(ssum);
+    if (cand_dist && lane == 0) cand_dist[c_] = dist;     // every candidate's distance, for callers that replay the scan
     const int lvl = t_level ? t_level[idx] : 0;
     if (dist < bd) { bd2 = bd; bd = dist; bl2 = bl; bl = lvl; bi = idx; }
     else if (dist < bd2) { bl2 = lvl; bd2 = dist; }
@@ -438,11 +439,11 @@ __global__ __launch_bounds__(64) void desc_best2_kernel(const float* q, const fl
 #pragma unroll
     for (int u = 0; u < 4; u++) sv[u] = wave_sum_f64(sq(b[u]));
 #pragma unroll
-    for (int u = 0; u < 4; u++) visit(sv[u], idx[u]);
+    for (int u = 0; u < 4; u++) visit(sv[u], idx[u], c + u);
   }
   for (; c < c1; c++) {
     const int idx = cand_idx[c];
-    visit(wave_sum_f64(sq(reinterpret_cast<const float4*>(t + (size_t)idx * 256)[lane])), idx);
+    visit(wave_sum_f64(sq(reinterpret_cast<const float4*>(t + (size_t)idx * 256)[lane])), idx, c);
   }
   if (lane == 0) {
     best_dist[qi] = bd; best_dist2[qi] = bd2; best_idx[qi] = bi; best_level[qi] = bl; best_level2[qi] = bl2;
@@ -451,10 +452,10 @@ __global__ __launch_bounds__(64) void desc_best2_kernel(const float* q, const fl
 
 void launch_desc_best2(const float* q, const float* t, const int32_t* t_level, const int32_t* cand_off,
                        const int32_t* cand_idx, int nq, float* best_dist, float* best_dist2, int32_t* best_idx,
-                       int32_t* best_level, int32_t* best_level2, hipStream_t s) {
+                       int32_t* best_level, int32_t* best_level2, float* cand_dist, hipStream_t s) {
   if (nq > 0)
     hipLaunchKernelGGL(desc_best2_kernel, dim3(nq), dim3(64), 0, s, q, t, t_level, cand_off, cand_idx, nq, best_dist, best_dist2,
-                       best_idx, best_level, best_level2);
+                       best_idx, best_level, best_level2, cand_dist);
 }
 
 }  // namespace dani

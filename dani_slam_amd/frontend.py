@@ -85,6 +85,7 @@ def load_library():
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_lg_attention_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
+    lib.dani_desc_scan.argtypes = [C.c_void_p, _f, C.c_int32, _f, C.c_int32, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _f]
     lib.dani_lg_linear_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
     lib.dani_lg_debug_fetch.argtypes = [C.c_void_p, C.c_int32, _f, _i32, _f, C.c_int32]
     lib.dani_yolo_detect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -414,6 +415,22 @@ class Engine:
         self._check(self.lib.dani_desc_best2(self.h, _fp(q), nq, _fp(t), nt, _ip(lvl) if lvl is not None else None, _ip(offs), _ip(idx),
                                              _fp(bd), _fp(bd2), _ip(bi), _ip(bl), _ip(bl2)))
         return bd, bd2, bi, bl, bl2
+
+    def desc_scan(self, q_desc, t_desc, t_level, cand_lists):
+        """desc_best2 plus the distance of every candidate (list of arrays aligned with cand_lists): what a host replay of
+        SearchByProjection's sequential claim logic needs (dani_desc_scan)."""
+        q = np.ascontiguousarray(q_desc, np.float32).reshape(-1, 256); t = np.ascontiguousarray(t_desc, np.float32).reshape(-1, 256)
+        nq, nt = len(q), len(t)
+        offs = np.zeros(nq + 1, np.int32)
+        offs[1:] = np.cumsum([len(cl) for cl in cand_lists])
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(cl, np.int32) for cl in cand_lists]) if offs[nq] else np.zeros(1, np.int32), np.int32)
+        lvl = np.ascontiguousarray(t_level, np.int32) if t_level is not None else None
+        bd = np.empty(nq, np.float32); bd2 = np.empty(nq, np.float32)
+        bi = np.empty(nq, np.int32); bl = np.empty(nq, np.int32); bl2 = np.empty(nq, np.int32)
+        cd = np.empty(max(int(offs[nq]), 1), np.float32)
+        self._check(self.lib.dani_desc_scan(self.h, _fp(q), nq, _fp(t), nt, _ip(lvl) if lvl is not None else None, _ip(offs), _ip(idx),
+                                            _fp(bd), _fp(bd2), _ip(bi), _ip(bl), _ip(bl2), _fp(cd)))
+        return (bd, bd2, bi, bl, bl2), [cd[offs[i]:offs[i + 1]] for i in range(nq)]
 
     def set_profiling(self, on=True):
         self._check(self.lib.dani_set_profiling(self.h, int(on)))

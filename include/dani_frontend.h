@@ -249,6 +249,16 @@ DANI_API int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, co
                              float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
                              int32_t* best_level2);
 
+/* Same scan, and additionally the distance of EVERY candidate (cand_dist[cand_offsets[nq]], aligned with cand_idx).
+ * SearchByProjection is sequential across map points: an accepted match claims its keypoint (F.mvpMapPoints[bestIdx] =
+ * pMP, src/LGmatcher.cpp:124) and later map points skip claimed keypoints (:92-94).  A caller that must reproduce that
+ * exactly replays the short selection loop on the host over these distances; the 256-float
+ * L2 norms -- the cost of the search -- are computed here once. */
+DANI_API int dani_desc_scan(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt,
+                            const int32_t* t_level, const int32_t* cand_offsets, const int32_t* cand_idx,
+                            float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
+                            int32_t* best_level2, float* cand_dist);
+
 /* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
 
 /* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.
