@@ -340,3 +340,90 @@ int yolo_dynamic_areas(const float* dets6, int n, int cols, int rows, const char
 }
 
 }  // namespace dani
+
+// ================================================================================================
+// feature hand-off formats (host, order-defining; literal restatements)
+// ================================================================================================
+namespace dani {
+
+// Frame::AssignFeaturesToGrid + Frame::PosInGrid (/root/reference/src/Frame.cc:387-418,727-737), case Nleft == -1:
+// posX = round((x - mnMinX) * mfGridElementWidthInv) with C round() (half away from zero); keypoints outside the grid
+// are dropped; mGrid[col][row] lists hold keypoint indices in ascending order.  CSR: cell = col * rows + row.
+void assign_features_to_grid(const float* kxy, int n, float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
+                             int32_t* cell_offsets, int32_t* cell_idx) {
+  std::vector<int> cell(n, -1), count((size_t)cols * rows + 1, 0);
+  for (int i = 0; i < n; i++) {
+    const int px = (int)std::round((kxy[2 * i] - min_x) * inv_w), py = (int)std::round((kxy[2 * i + 1] - min_y) * inv_h);
+    if (px < 0 || px >= cols || py < 0 || py >= rows) continue;
+    cell[i] = px * rows + py;
+    count[cell[i] + 1]++;
+  }
+  for (int c = 0; c < cols * rows; c++) count[c + 1] += count[c];
+  for (int c = 0; c <= cols * rows; c++) cell_offsets[c] = count[c];
+  std::vector<int> fill(count.begin(), count.end() - 1);
+  for (int i = 0; i < n; i++)
+    if (cell[i] >= 0) cell_idx[fill[cell[i]]++] = i;
+}
+
+// Frame::GetFeaturesInArea (src/Frame.cc:659-725) for one query window; appends to `out` in the reference's order
+// (cells ix outer / iy inner, cell lists in index order); returns false when the window misses the grid.
+void features_in_area(const float* kxy, const int32_t* octave, float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
+                      const int32_t* cell_offsets, const int32_t* cell_idx, float x, float y, float r, int min_level, int max_level,
+                      std::vector<int32_t>& out) {
+  const int nMinCellX = std::max(0, (int)std::floor((x - min_x - r) * inv_w));
+  if (nMinCellX >= cols) return;
+  const int nMaxCellX = std::min(cols - 1, (int)std::ceil((x - min_x + r) * inv_w));
+  if (nMaxCellX < 0) return;
+  const int nMinCellY = std::max(0, (int)std::floor((y - min_y - r) * inv_h));
+  if (nMinCellY >= rows) return;
+  const int nMaxCellY = std::min(rows - 1, (int)std::ceil((y - min_y + r) * inv_h));
+  if (nMaxCellY < 0) return;
+  const bool check_levels = (min_level > 0) || (max_level >= 0);
+  for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+    for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+      const int c = ix * rows + iy;
+      for (int j = cell_offsets[c]; j < cell_offsets[c + 1]; j++) {
+        const int k = cell_idx[j];
+        if (check_levels) {
+          const int o = octave ? octave[k] : 0;
+          if (o < min_level) continue;
+          if (max_level >= 0 && o > max_level) continue;
+        }
+        const float distx = kxy[2 * k] - x, disty = kxy[2 * k + 1] - y;
+        if (std::fabs(distx) < r && std::fabs(disty) < r) out.push_back(k);
+      }
+    }
+}
+
+// Frame::ComputeStereoMatches after the LightGlue call (src/Frame.cc:862-914): disparity gate [0, mbf / mb), depth =
+// mbf / max-ish(disparity) (non-positive -> 0.01), then the matches whose (1 - score) reaches 1.5 x the median of the
+// sorted (distance, left index) pairs are cleared again.
+void stereo_from_matches(const float* ul_x, int nl, const float* ur_x, int nr, const int32_t* matches, const float* scores, int k,
+                         float mb, float mbf, float* u_right, float* depth) {
+  for (int i = 0; i < nl; i++) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+  const float minZ = mb, minD = 0, maxD = mbf / minZ;
+  std::vector<std::pair<float, int>> disp;
+  disp.reserve(k);
+  for (int m = 0; m < k; m++) {
+    const int iL = matches[2 * m], iR = matches[2 * m + 1];
+    if (iL >= nl || iR >= nr || iL < 0 || iR < 0) continue;
+    const float uL = ul_x[iL], uR = ur_x[iR];
+    float disparity = uL - uR;
+    if (disparity >= minD && disparity < maxD) {
+      if (disparity <= 0) disparity = 0.01;
+      depth[iL] = mbf / disparity;
+      u_right[iL] = uR;
+      disp.push_back(std::make_pair(1.0f - scores[m], iL));
+    }
+  }
+  if (disp.empty()) return;
+  std::sort(disp.begin(), disp.end());
+  const float median = disp[disp.size() / 2].first, th = 1.5f * median;
+  for (int i = (int)disp.size() - 1; i >= 0; i--) {
+    if (disp[i].first < th) break;
+    u_right[disp[i].second] = -1;
+    depth[disp[i].second] = -1;
+  }
+}
+
+}  // namespace dani

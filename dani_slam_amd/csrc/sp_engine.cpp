@@ -464,6 +464,37 @@ int dani_host_cell_grid(int32_t width, int32_t height, int32_t* cells6, int32_t 
   return n;
 }
 
+int dani_host_assign_features_to_grid(const float* kpts_xy, int32_t n, const dani_grid* g, int32_t* cell_offsets, int32_t* cell_idx) {
+  if (n < 0 || (n && !kpts_xy) || !g || g->cols < 1 || g->rows < 1 || !cell_offsets || (n && !cell_idx)) return DANI_ERR_INVALID;
+  assign_features_to_grid(kpts_xy, n, g->min_x, g->min_y, g->inv_w, g->inv_h, g->cols, g->rows, cell_offsets, cell_idx);
+  return cell_offsets[g->cols * g->rows];
+}
+
+int dani_host_features_in_area(const float* kpts_xy, const int32_t* octave, int32_t n, const dani_grid* g, const int32_t* cell_offsets,
+                               const int32_t* cell_idx, const float* qx, const float* qy, const float* qr, const int32_t* min_level,
+                               const int32_t* max_level, int32_t nq, int32_t* cand_offsets, int32_t* cand_idx, int32_t cap) {
+  if (n < 0 || nq < 0 || !g || !cell_offsets || (n && (!kpts_xy || !cell_idx)) || (nq && (!qx || !qy || !qr)) || !cand_offsets || cap < 0)
+    return DANI_ERR_INVALID;
+  std::vector<int32_t> out;
+  cand_offsets[0] = 0;
+  for (int q = 0; q < nq; q++) {
+    features_in_area(kpts_xy, octave, g->min_x, g->min_y, g->inv_w, g->inv_h, g->cols, g->rows, cell_offsets, cell_idx, qx[q], qy[q], qr[q],
+                     min_level ? min_level[q] : -1, max_level ? max_level[q] : -1, out);
+    cand_offsets[q + 1] = (int32_t)out.size();
+  }
+  if ((int)out.size() > cap) return DANI_ERR_CAPACITY;
+  if (!out.empty()) memcpy(cand_idx, out.data(), out.size() * 4);
+  return (int)out.size();
+}
+
+int dani_host_stereo_from_matches(const float* ul_x, int32_t nl, const float* ur_x, int32_t nr, const int32_t* matches,
+                                  const float* scores, int32_t k, float mb, float mbf, float* u_right, float* depth) {
+  if (nl < 0 || nr < 0 || k < 0 || (nl && (!ul_x || !u_right || !depth)) || (nr && !ur_x) || (k && (!matches || !scores)) || !(mb > 0.0f))
+    return DANI_ERR_INVALID;
+  stereo_from_matches(ul_x, nl, ur_x, nr, matches, scores, k, mb, mbf, u_right, depth);
+  return DANI_OK;
+}
+
 int dani_host_features_per_level(int32_t nfeatures, float scale_factor, int32_t nlevels, int32_t* per_level,
                                  float* scale_factors) {
   if (nlevels < 1 || !per_level) return DANI_ERR_INVALID;

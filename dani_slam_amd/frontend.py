@@ -145,6 +145,55 @@ def host_features_per_level(nfeatures, scaleFactor, nlevels):
     return per, sc
 
 
+class _Grid(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("inv_w", C.c_float), ("inv_h", C.c_float), ("cols", C.c_int32), ("rows", C.c_int32)]
+
+
+def host_assign_features_to_grid(kxy, min_x, min_y, inv_w, inv_h, cols=64, rows=48):
+    """Frame::AssignFeaturesToGrid (src/Frame.cc:387-418): CSR (cell_offsets [cols*rows+1], cell_idx), cell = col*rows + row."""
+    lib = load_library()
+    kxy = np.ascontiguousarray(kxy, np.float32).reshape(-1, 2)
+    g = _Grid(min_x, min_y, inv_w, inv_h, cols, rows)
+    offs = np.zeros(cols * rows + 1, np.int32); idx = np.zeros(max(len(kxy), 1), np.int32)
+    m = lib.dani_host_assign_features_to_grid(_fp(kxy), len(kxy), C.byref(g), _ip(offs), _ip(idx))
+    if m < 0:
+        raise DaniError(m, "dani_host_assign_features_to_grid")
+    return offs, idx[:m].copy()
+
+
+def host_features_in_area(kxy, octave, grid_params, cell_offsets, cell_idx, qx, qy, qr, min_level=None, max_level=None, cap=1 << 22):
+    """Frame::GetFeaturesInArea (src/Frame.cc:659-725) for many windows: returns a list of candidate index arrays."""
+    lib = load_library()
+    kxy = np.ascontiguousarray(kxy, np.float32).reshape(-1, 2)
+    g = _Grid(*grid_params)
+    qx = np.ascontiguousarray(qx, np.float32); qy = np.ascontiguousarray(qy, np.float32); qr = np.ascontiguousarray(qr, np.float32)
+    nq = len(qx)
+    octv = np.ascontiguousarray(octave, np.int32) if octave is not None else None
+    mn = np.ascontiguousarray(min_level, np.int32) if min_level is not None else None
+    mx = np.ascontiguousarray(max_level, np.int32) if max_level is not None else None
+    offs = np.zeros(nq + 1, np.int32); idx = np.zeros(cap, np.int32)
+    cell_offsets = np.ascontiguousarray(cell_offsets, np.int32); cell_idx = np.ascontiguousarray(cell_idx, np.int32)
+    m = lib.dani_host_features_in_area(_fp(kxy), _ip(octv) if octv is not None else None, len(kxy), C.byref(g), _ip(cell_offsets),
+                                       _ip(cell_idx) if len(cell_idx) else None, _fp(qx), _fp(qy), _fp(qr),
+                                       _ip(mn) if mn is not None else None, _ip(mx) if mx is not None else None, nq, _ip(offs), _ip(idx), cap)
+    if m < 0:
+        raise DaniError(m, "dani_host_features_in_area")
+    return [idx[offs[i]:offs[i + 1]].copy() for i in range(nq)]
+
+
+def host_stereo_from_matches(ul_x, ur_x, matches, scores, mb, mbf):
+    """Frame::ComputeStereoMatches post-filter (src/Frame.cc:862-914): returns (mvuRight, mvDepth)."""
+    lib = load_library()
+    ul = np.ascontiguousarray(ul_x, np.float32); ur = np.ascontiguousarray(ur_x, np.float32)
+    m = np.ascontiguousarray(matches, np.int32).reshape(-1, 2); s = np.ascontiguousarray(scores, np.float32)
+    u_right = np.empty(max(len(ul), 1), np.float32); depth = np.empty(max(len(ul), 1), np.float32)
+    rc = lib.dani_host_stereo_from_matches(_fp(ul), len(ul), _fp(ur), len(ur), _ip(m) if len(m) else None, _fp(s) if len(m) else None,
+                                           len(m), C.c_float(mb), C.c_float(mbf), _fp(u_right), _fp(depth))
+    if rc:
+        raise DaniError(rc, "dani_host_stereo_from_matches")
+    return u_right[:len(ul)], depth[:len(ul)]
+
+
 def host_dynamic_areas(dets6, cols, rows, class_names, dynamic_names):
     """Detect()'s box bookkeeping + RefineDynamicBoxes (src/YoloDetect.cpp:51-80,148-208).
     Returns (dynamic boxes [k,4] int32, det rects [n,4] int32)."""

@@ -269,6 +269,30 @@ DANI_API int dani_host_distribute_octtree(const float* in_xyr, int32_t n, int32_
 /* The cell grid of ComputeKeyPointsOctTree (src/SPextractor.cpp:232-266) for an image size: writes up to
  * cap cells as (iniX, maxX, iniY, maxY, offX, offY) and returns the number of non-skipped cells. */
 DANI_API int dani_host_cell_grid(int32_t width, int32_t height, int32_t* cells6, int32_t cap);
+
+/* ---- feature hand-off formats (host, order-defining) ---------------- */
+
+/* Frame's keypoint grid: FRAME_GRID_COLS x FRAME_GRID_ROWS (64 x 48, include/Frame.h:52-53) over the undistorted
+ * image bounds; inv_w = cols / (mnMaxX - mnMinX), inv_h = rows / (mnMaxY - mnMinY) as floats (src/Frame.cc:253-254). */
+typedef struct dani_grid { float min_x, min_y, inv_w, inv_h; int32_t cols, rows; } dani_grid;
+
+/* Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:387-418,727-737; monocular / RGB-D case): CSR over the cells in
+ * mGrid[col][row] order (cell = col * rows + row): cell_offsets[cols*rows + 1], cell_idx[<= n] = keypoint indices in
+ * ascending order per cell; keypoints that round outside the grid are dropped.  Returns the number of indices written. */
+DANI_API int dani_host_assign_features_to_grid(const float* kpts_xy, int32_t n, const dani_grid* g, int32_t* cell_offsets,
+                                               int32_t* cell_idx);
+/* Frame::GetFeaturesInArea (src/Frame.cc:659-725) for nq windows (x, y, r, minLevel, maxLevel; NULL levels = -1) at once:
+ * CSR candidate lists in the reference's order (cells ix outer / iy inner, cell lists in index order) -- the input of
+ * dani_desc_best2 / dani_desc_scan.  Returns the total number of candidates, DANI_ERR_CAPACITY if it exceeds cap. */
+DANI_API int dani_host_features_in_area(const float* kpts_xy, const int32_t* octave, int32_t n, const dani_grid* g,
+                                        const int32_t* cell_offsets, const int32_t* cell_idx, const float* qx, const float* qy,
+                                        const float* qr, const int32_t* min_level, const int32_t* max_level, int32_t nq,
+                                        int32_t* cand_offsets, int32_t* cand_idx, int32_t cap);
+/* Frame::ComputeStereoMatches after its LightGlue call (src/Frame.cc:862-914): mvuRight / mvDepth (nl entries, -1 =
+ * none) from the (left, right) matches and scores of dani_lg_match: disparity gate [0, mbf / mb), depth = mbf /
+ * disparity, then every match whose (1 - score) reaches 1.5 x the median is cleared again. */
+DANI_API int dani_host_stereo_from_matches(const float* ul_x, int32_t nl, const float* ur_x, int32_t nr, const int32_t* matches,
+                                           const float* scores, int32_t k, float mb, float mbf, float* u_right, float* depth);
 /* mnFeaturesPerLevel / mvScaleFactor tables (src/SPextractor.cpp:97-126). */
 DANI_API int dani_host_features_per_level(int32_t nfeatures, float scale_factor, int32_t nlevels, int32_t* per_level,
                                           float* scale_factors);

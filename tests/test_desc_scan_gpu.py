@@ -69,3 +69,32 @@ def test_search_by_projection_replay_over_gpu_distances(sp_weights):
     free = [int(b) for b, d_ in zip(bi, bd) if b >= 0 and d_ <= mo.TH_HIGH]
     assert len(free) > len(set(free))
     e.close()
+
+
+def test_projection_search_pipeline(sp_weights):
+    """Rank 1 + 2 chained as a tracking thread would: Frame's keypoint grid -> GetFeaturesInArea windows around the
+    projected map points -> descriptor distances on the GPU -> sequential selection replay; against the oracle chain."""
+    from dani_slam_amd import frontend
+    from oracle import handoff_oracle as ho
+    e = frontend.Engine(device=0, weights=sp_weights)
+    rng = np.random.RandomState(9)
+    k0, d0, k1, d1, gt = synth.matching_pair(12, n0=900, n1=1025)
+    octave = np.zeros(len(k1), np.int32)
+    inv_w, inv_h = np.float32(64) / np.float32(640), np.float32(48) / np.float32(480)
+    grid_params = (0.0, 0.0, float(inv_w), float(inv_h), 64, 48)
+    offs, idx = frontend.host_assign_features_to_grid(k1, *grid_params)
+    # "projections" of the map points: their true keypoint position in the frame plus noise, or a random place
+    proj = np.where(gt[:, None] >= 0, k1[np.maximum(gt, 0)] + rng.normal(0, 2.0, (len(k0), 2)), rng.uniform(0, 640, (len(k0), 2))).astype(np.float32)
+    r = np.full(len(k0), 15.0, np.float32)
+    lists = frontend.host_features_in_area(k1, octave, grid_params, offs, idx, proj[:, 0], proj[:, 1], r, np.full(len(k0), -1, np.int32), np.zeros(len(k0), np.int32))
+    grid = ho.assign_features_to_grid(k1, 0.0, 0.0, inv_w, inv_h)
+    ref_lists = [ho.get_features_in_area(k1, octave, grid, 0.0, 0.0, inv_w, inv_h, proj[i, 0], proj[i, 1], r[i], -1, 0) for i in range(len(k0))]
+    assert [l.tolist() for l in lists] == ref_lists
+    q = d0 * np.float32(0.45); t = d1 * np.float32(0.45)
+    best, dist = e.desc_scan(q, t, octave, [l.tolist() for l in lists])
+    got = mo.search_by_projection(q, t, octave, ref_lists, 0.8, dist=dist)
+    ref = mo.search_by_projection(q, t, octave, ref_lists, 0.8)
+    assert got == ref
+    good = sum(1 for qi, ki in ref if gt[qi] == ki)
+    assert good > 0.9 * len(ref) and len(ref) > 500
+    e.close()
