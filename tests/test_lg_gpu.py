@@ -57,7 +57,7 @@ def _check_pair(engine, w, k0, d0, k1, d1, size0=SIZE, size1=SIZE, thr=0.05):
     return m, s, mo, so
 
 
-@pytest.mark.parametrize("n0,n1", [(1024, 1024), (128, 128), (7, 7), (1025, 1000), (33, 700), (1025, 1025), (40, 1030), (64, 70)])
+@pytest.mark.parametrize("n0,n1", [(1024, 1024), (128, 128), (7, 7), (1025, 1000), (33, 700), (1025, 1025), (40, 1030), (64, 70), (1027, 1028), (35, 36)])
 def test_pair_matches_oracle(engine, lg_weights, n0, n1):
     k0, d0, k1, d1, gt = synth.matching_pair(n0 + n1, n0=n0, n1=n1)
     m, s, mo, so = _check_pair(engine, lg_weights, k0, d0, k1, d1)
@@ -94,6 +94,28 @@ def test_batch_equals_single(engine, lg_weights):
         m, s = engine.lg_match(k0, d0, k1, d1, SIZE, SIZE, 0.05)
         assert np.array_equal(res[p][0], m)
         np.testing.assert_allclose(res[p][1], s, rtol=0, atol=1e-6)
+
+
+def test_large_batch_kernel_with_ragged_sets(lg_weights, sp_weights):
+    """32 keypoint sets of ~1024 keypoints take the 128-query-tile attention kernel (attn_kernel<4>) instead of the
+    key-split one: its tail-key / tail-query paths (sets of 1025..1028 keypoints) must give what the single-pair path gives."""
+    from dani_slam_amd import frontend
+    w = dict(sp_weights); w.update(lg_weights)
+    e = frontend.Engine(device=0, weights=w, max_batch=16)
+    sizes = [(1025, 1027), (1024, 1028), (1026, 1025), (1000, 1025)] * 4
+    pairs = [synth.matching_pair(70 + i, n0=a, n1=b) for i, (a, b) in enumerate(sizes)]
+    cap = 1028
+    K0 = np.zeros((16, cap, 2), np.float32); D0 = np.zeros((16, cap, 256), np.float32)
+    K1 = np.zeros((16, cap, 2), np.float32); D1 = np.zeros((16, cap, 256), np.float32)
+    for p, (k0, d0, k1, d1, _) in enumerate(pairs):
+        K0[p, :len(k0)] = k0; D0[p, :len(k0)] = d0; K1[p, :len(k1)] = k1; D1[p, :len(k1)] = d1
+    res = e.lg_match_batch(K0, D0, [a for a, _ in sizes], K1, D1, [b for _, b in sizes], SIZE, SIZE, 0.05)
+    for p in (0, 1, 2, 3, 9, 15):
+        k0, d0, k1, d1, _ = pairs[p]
+        m, s = e.lg_match(k0, d0, k1, d1, SIZE, SIZE, 0.05)
+        assert np.array_equal(res[p][0], m), p
+        np.testing.assert_allclose(res[p][1], s, rtol=0, atol=1e-4)      # two kernels, two summation orders
+    e.close()
 
 
 def test_reference_style_wrapper(engine, lg_weights):
