@@ -352,6 +352,34 @@ __device__ __forceinline__ AttnKeys attn_keys(const LgSet& st, int cross) {
   return k;
 }
 
+// S^T[key][query] += K[key][d] Q[query][d] over the 64 d of one staged tile, and O^T[d][query] += V[key][d] P[query][key]:
+// the LDS operand reads of group g + 1 are issued before the MFMAs of group g (left alone, hipcc sinks every read next
+// to its MFMA and waits on it; measured 151 -> 145.5 us per launch at 16 x 1024 keypoints, tools/probes/attn_probe.hip).
+__device__ __forceinline__ void attn_qk_tile(const float* sK, const float (&qreg)[32], f32x16& s, int j, int h) {
+  float kv[16][2];
+  kv[0][0] = sK[(0 + h) * AT_STRIDE + j]; kv[0][1] = sK[(2 + h) * AT_STRIDE + j];
+#pragma unroll
+  for (int g = 0; g < 16; g++) {
+    if (g + 1 < 16) { kv[g + 1][0] = sK[(4 * (g + 1) + h) * AT_STRIDE + j]; kv[g + 1][1] = sK[(4 * (g + 1) + 2 + h) * AT_STRIDE + j]; }
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[g][0], qreg[2 * g], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[g][1], qreg[2 * g + 1], s, 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+  }
+}
+__device__ __forceinline__ void attn_pv_tile(const float* sV, const f32x16& s, f32x16 (&o)[2], int j, int h) {
+  float vv[16][2];   // P^T accumulator register r is the B operand of step r
+  vv[0][0] = sV[j * AT_STRIDE + acc_row(0, h)]; vv[0][1] = sV[(32 + j) * AT_STRIDE + acc_row(0, h)];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    if (r + 1 < 16) { vv[r + 1][0] = sV[j * AT_STRIDE + acc_row(r + 1, h)]; vv[r + 1][1] = sV[(32 + j) * AT_STRIDE + acc_row(r + 1, h)]; }
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r][0], s[r], o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r][1], s[r], o[1], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+  }
+}
+
 // The key set's tail keys (at most LG_TAIL_MAX), folded into a 32-query wave's online-softmax state on the VALU:
 // one key costs ~130 VALU/LDS ops against the 64 MFMAs of a whole key tile.  Their K / V columns are staged once per
 // workgroup in LDS (`tk`: [key][K 64 | V 64], loaded with the query prologue); every read below is a broadcast.
@@ -512,13 +540,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const float* Q, const 
     if (kt + 1 < ntiles) AT_PREFETCH(kt + 1);
 
     // S^T[key][query] = sum_d K[key][d] Q[query][d]
-    // (tried: hoisting all 32 operand reads + two accumulator chains behind sched_barrier -> 199 VGPRs, 2 waves/SIMD,
-    //  254 us vs 228 us per launch; the loss here is wave-count quantisation over the 1024 SIMDs, not the chain)
+    // (hoisting ALL 32 operand reads + two accumulator chains cost 199 VGPRs and was slower; reading ONE group ahead,
+    //  attn_qk_tile, is the version that pays)
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; r++) s[r] = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 32; t++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(2 * t + h) * AT_STRIDE + j], qreg[t], s, 0, 0, 0);
+    attn_qk_tile(sK, qreg, s, j, h);
 
     const int kbase = kt * 32;
     float mx = -1e30f;
@@ -538,12 +565,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_kernel(const float* Q, const 
 #pragma unroll
     for (int r = 0; r < 16; r++) { o[0][r] *= alpha; o[1][r] *= alpha; }
     // O^T[d][query] += sum_key V[key][d] P[query][key]; P^T accumulator register r is the B operand of step r
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int key = acc_row(r, h);
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[j * AT_STRIDE + key], s[r], o[0], 0, 0, 0);
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(32 + j) * AT_STRIDE + key], s[r], o[1], 0, 0, 0);
-    }
+    attn_pv_tile(sV, s, o, j, h);
   }
 #undef AT_PREFETCH
   if (ks.n > ks.nmain) {
@@ -641,8 +663,7 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; r++) s[r] = 0.0f;
-#pragma unroll
-      for (int t = 0; t < 32; t++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(2 * t + h) * AT_STRIDE + j], qreg[t], s, 0, 0, 0);
+      attn_qk_tile(sK, qreg, s, j, h);
       const int kbase = kt * 32;
       if (kbase + 32 > k_n) {                               // only the last key tile can hold padding keys
 #pragma unroll
@@ -665,12 +686,7 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
       }
       l += ls;
       m = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = acc_row(r, h);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[j * AT_STRIDE + key], s[r], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(32 + j) * AT_STRIDE + key], s[r], o[1], 0, 0, 0);
-      }
+      attn_pv_tile(sV, s, o, j, h);
     }
   }
 #undef ATK_PREFETCH

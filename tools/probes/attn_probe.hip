@@ -12,7 +12,7 @@ struct LgSet { int tok_off, n, partner_off, partner_n; float size_w, size_h; con
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 constexpr int AT_STRIDE = 33;
 
-enum { F_XCD = 1, F_NOSOFTMAX = 2, F_NOSTAGE = 4, F_NOPV = 8, F_NOS = 16, F_NOBAR = 32, F_PRIO_SLOT = 64, F_PRIO_ODD = 128, F_PRIO_PHASE = 256, F_PRIO_PV = 512, F_PRIO_LOW1 = 1024 };
+enum { F_XCD = 1, F_NOSOFTMAX = 2, F_NOSTAGE = 4, F_NOPV = 8, F_NOS = 16, F_NOBAR = 32, F_PRIO_SLOT = 64, F_PRIO_ODD = 128, F_PRIO_PHASE = 256, F_PRIO_PV = 512, F_PRIO_LOW1 = 1024, F_PIPE = 2048 };
 
 template <int OCC, int FLAGS>
 __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
@@ -94,8 +94,21 @@ __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, co
       for (int r = 0; r < 16; r++) s[r] = (FLAGS & F_NOS) ? qreg[r] : 0.0f;
       if (FLAGS & F_PRIO_PHASE) __builtin_amdgcn_s_setprio(3);
       if (!(FLAGS & F_NOS)) {
+        if (FLAGS & F_PIPE) {   // operand reads one group (2 k-steps) ahead of the MFMAs
+          float kv[16][2];
+          kv[0][0] = sK[(0 + h) * AT_STRIDE + j]; kv[0][1] = sK[(2 + h) * AT_STRIDE + j];
+#pragma unroll
+          for (int g = 0; g < 16; g++) {
+            if (g + 1 < 16) { kv[g + 1][0] = sK[(4 * (g + 1) + h) * AT_STRIDE + j]; kv[g + 1][1] = sK[(4 * (g + 1) + 2 + h) * AT_STRIDE + j]; }
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[g][0], qreg[2 * g], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[g][1], qreg[2 * g + 1], s, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+        } else {
 #pragma unroll
         for (int t = 0; t < 32; t++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[(2 * t + h) * AT_STRIDE + j], qreg[t], s, 0, 0, 0);
+        }
       }
       if (FLAGS & F_PRIO_PHASE) __builtin_amdgcn_s_setprio(0);
       if (!(FLAGS & F_NOSOFTMAX)) {
@@ -126,11 +139,24 @@ __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, co
       }
       if (FLAGS & F_PRIO_PV) __builtin_amdgcn_s_setprio(3);
       if (!(FLAGS & F_NOPV)) {
+        if (FLAGS & F_PIPE) {
+          float vv[16][2];
+          vv[0][0] = sV[j * AT_STRIDE + acc_row(0, h)]; vv[0][1] = sV[(32 + j) * AT_STRIDE + acc_row(0, h)];
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if (r + 1 < 16) { vv[r + 1][0] = sV[j * AT_STRIDE + acc_row(r + 1, h)]; vv[r + 1][1] = sV[(32 + j) * AT_STRIDE + acc_row(r + 1, h)]; }
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r][0], s[r], o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r][1], s[r], o[1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int key = acc_row(r, h);
           o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[j * AT_STRIDE + key], s[r], o[0], 0, 0, 0);
           o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[(32 + j) * AT_STRIDE + key], s[r], o[1], 0, 0, 0);
+        }
         }
       } else {
 #pragma unroll
@@ -166,18 +192,11 @@ __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, co
 }
 
 #define VARIANTS \
-RUN(2, 0, "baseline") \
-  RUN(2, F_XCD, "XCD") \
-  RUN(2, F_XCD | F_PRIO_SLOT, "XCD + prio slot(2)") \
-  RUN(2, F_XCD | F_PRIO_SLOT | F_PRIO_LOW1, "XCD + prio slot(1)") \
-  RUN(2, F_XCD | F_PRIO_PHASE, "XCD + phase prio (S hi, rest lo)") \
-  RUN(2, F_XCD | F_PRIO_PHASE | F_PRIO_PV, "XCD + phase prio (S, PV hi; softmax, staging lo)") \
-  RUN(2, F_XCD | F_PRIO_PV, "XCD + PV hi, rest lo") \
-  RUN(3, F_XCD | F_PRIO_PHASE, "3 WG/CU + XCD + phase prio") \
-  RUN(3, F_XCD | F_PRIO_PHASE | F_PRIO_PV, "3 WG/CU + XCD + phase prio S,PV") \
-  RUN(3, F_PRIO_PHASE, "3 WG/CU + phase prio") \
-  RUN(4, F_XCD, "4 WG/CU + XCD") \
-  RUN(4, F_XCD | F_PRIO_PHASE, "4 WG/CU + XCD + phase prio")
+  RUN(2, 0, "baseline") \
+  RUN(2, F_PIPE, "operand reads one group ahead") \
+  RUN(2, F_NOSTAGE | F_NOSOFTMAX, "MFMA + LDS reads only") \
+  RUN(2, F_NOSTAGE | F_NOSOFTMAX | F_PIPE, "MFMA + LDS reads only, reads ahead") \
+  RUN(2, 0, "baseline again")
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
