@@ -833,12 +833,14 @@ __global__ __launch_bounds__(64) void row_lse_kernel(const float* sim, int sim_l
   if (threadIdx.x == 0) lse_row[s0.dense_off + i] = mx + __logf(sm);
 }
 
-// column statistics + column argmax of (2*sim - lse_row[i] + ls0[i]): thread per column, 4-way row split per block
-__global__ __launch_bounds__(256) void col_stats_kernel(const float* sim, int sim_ld, size_t pstride, const LgSet* sets,
+// column statistics + column argmax of (2*sim - lse_row[i] + ls0[i]): thread per column, CS_SPLIT-way row split per
+// block (64 columns x 16 row groups = 1024 threads: the 4-way version left 136 workgroups of 4 waves for the chip)
+constexpr int CS_SPLIT = 16;
+__global__ __launch_bounds__(64 * CS_SPLIT) void col_stats_kernel(const float* sim, int sim_ld, size_t pstride, const LgSet* sets,
                                                         const float* lse_row, const float* logsig, float* lse_col,
                                                         int* m1, int ld) {
-  __shared__ float rmx[4][64], rsm[4][64], rbv[4][64];
-  __shared__ int rbi[4][64];
+  __shared__ float rmx[CS_SPLIT][64], rsm[CS_SPLIT][64], rbv[CS_SPLIT][64];
+  __shared__ int rbi[CS_SPLIT][64];
   const int pair = blockIdx.y;
   const LgSet s0 = sets[2 * pair], s1 = sets[2 * pair + 1];
   const int lj = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* sim, int si
   // pass 1: max over rows (online logsumexp) and best score
   float mx = -1e30f, sm = 0.0f, bv = -3e38f;
   int bi = 0;
-  for (int i = q; i < s0.n; i += 4) {
+  for (int i = q; i < s0.n; i += CS_SPLIT) {
     const float v = sp[(size_t)i * sim_ld];
     const float nm = fmaxf(mx, v);
     sm = sm * __expf(mx - nm) + __expf(v - nm);
@@ -860,12 +862,12 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* sim, int si
   __syncthreads();
   if (q == 0 && ok) {
     float M = rmx[0][lj];
-    for (int k = 1; k < 4; k++) M = fmaxf(M, rmx[k][lj]);
+    for (int k = 1; k < CS_SPLIT; k++) M = fmaxf(M, rmx[k][lj]);
     float S = 0.0f;
-    for (int k = 0; k < 4; k++) S += rsm[k][lj] * __expf(rmx[k][lj] - M);
+    for (int k = 0; k < CS_SPLIT; k++) S += rsm[k][lj] * __expf(rmx[k][lj] - M);
     lse_col[s1.dense_off + jj] = M + __logf(S);
     float B = rbv[0][lj]; int I = rbi[0][lj];
-    for (int k = 1; k < 4; k++)
+    for (int k = 1; k < CS_SPLIT; k++)
       if (rbv[k][lj] > B || (rbv[k][lj] == B && rbi[k][lj] < I)) { B = rbv[k][lj]; I = rbi[k][lj]; }
     m1[s1.dense_off + jj] = I;
   }
@@ -900,7 +902,7 @@ void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const
                              const float* logsig, float* lse_row, float* lse_col, int* m0, float* max0, int* m1, int ld,
                              hipStream_t s) {
   hipLaunchKernelGGL(row_lse_kernel, dim3(max_n, npairs), dim3(64), 0, s, sim, sim_ld, pstride, sets, lse_row, ld);
-  hipLaunchKernelGGL(col_stats_kernel, dim3((max_n + 63) / 64, npairs), dim3(256), 0, s, sim, sim_ld, pstride, sets, lse_row,
+  hipLaunchKernelGGL(col_stats_kernel, dim3((max_n + 63) / 64, npairs), dim3(64 * CS_SPLIT), 0, s, sim, sim_ld, pstride, sets, lse_row,
                      logsig, lse_col, m1, ld);
   hipLaunchKernelGGL(row_argmax_kernel, dim3(max_n, npairs), dim3(64), 0, s, sim, sim_ld, pstride, sets, lse_row, lse_col,
                      logsig, m0, max0);
