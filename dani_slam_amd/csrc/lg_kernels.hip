@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   }
 }
 
-int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = heuristic below)
+int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = the 64-token tile)
 
 void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
@@ -203,13 +203,12 @@ void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w_packed; a.bias = bias_packed; a.y = y; a.res = res;
   a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;
   const int otiles = (OUT + LIN_NCO - 1) / LIN_NCO;
-  // Largest token tile that still yields >= 16 workgroups per CU, else the smallest: measured on the LightGlue shapes
-  // (tools/probes/lin_bench.hip, 16 x 1025 keypoints) the 64-token tile -- 86 VGPRs, 32 KB LDS, 5 workgroups per CU --
-  // beats the 128-token one (121 VGPRs, 48 KB, 3 per CU) by 9-15 % until the grid is several rounds deep.
-  auto wgs = [&](int tt) { return ((T + tt - 1) / tt) * otiles; };
+  // The 64-token tile (90 VGPRs, 32 KB LDS, 5 workgroups per CU) beats the 128- and 256-token ones (128 / 148 VGPRs,
+  // 48 KB, 3 per CU) on every LightGlue shape from 16 k to 66 k tokens by 7-17 % (tools/probes/lin_bench.hip), so it is
+  // always used; the larger instantiations stay reachable through the probe's tuning hook.
   auto grid = [&](int tt) { return dim3((unsigned)(((T + tt - 1) / tt + 7) / 8 * 8 * otiles)); };   // see the kernel: 8 XCDs
-  if (g_lin_force_tt == 256 || (!g_lin_force_tt && wgs(256) >= 4096)) hipLaunchKernelGGL(linear_fm_kernel<256>, grid(256), dim3(256), 0, s, a);
-  else if (g_lin_force_tt == 128 || (!g_lin_force_tt && wgs(128) >= 4096)) hipLaunchKernelGGL(linear_fm_kernel<128>, grid(128), dim3(256), 0, s, a);
+  if (g_lin_force_tt == 256) hipLaunchKernelGGL(linear_fm_kernel<256>, grid(256), dim3(256), 0, s, a);
+  else if (g_lin_force_tt == 128) hipLaunchKernelGGL(linear_fm_kernel<128>, grid(128), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(linear_fm_kernel<64>, grid(64), dim3(256), 0, s, a);
 }
 

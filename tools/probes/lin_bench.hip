@@ -13,7 +13,7 @@ int main(int argc, char** argv) {
   std::vector<int> Ts;
   for (int i = 1; i < argc; i++) Ts.push_back(atoi(argv[i]));
   if (Ts.empty()) Ts = {16384, 16416, 16448, 16896};
-  const int ld = 17920;
+  const int ld = 70000;
   float *X, *Y, *Wt, *Bs, *C;
   CK(hipMalloc(&X, (size_t)1024 * ld * 4)); CK(hipMalloc(&Y, (size_t)768 * ld * 4)); CK(hipMalloc(&Wt, (size_t)768 * 512 * 4));
   CK(hipMalloc(&Bs, 768 * 4)); CK(hipMalloc(&C, (size_t)64 * ld * 4));
