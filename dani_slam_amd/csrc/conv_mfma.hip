@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
   float* sIn = lds;
   float* sW = lds + C::CC * C::LROWS * C::RS;
+  // The SiLU instantiations are YOLOv5s layers: a chain of ~60 small dependent launches that runs concurrently with
+  // SuperPoint's few huge ones and is the critical path of that phase.  Raise their waves' issue priority so that a
+  // YOLO workgroup sharing a SIMD with SuperPoint waves is not slowed to their pace.
+  if constexpr (C::ACT == ACT_SILU) __builtin_amdgcn_s_setprio(3);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
