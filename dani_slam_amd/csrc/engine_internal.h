@@ -68,6 +68,7 @@ struct Context {
   int kcap = 0;
   // pinned host staging
   float* h_kxy = nullptr;  // [B][kcap][2] followed by per-level (offset, count) ints [nlevels][2][B]
+  bool cands_enqueued = false;   // phase 1 already ran cell NMS + candidate read-back (SpCall::host_cull)
   float* h_desc = nullptr; // [B][kcap][256]: descriptor read-back of the fused call (copied out under LightGlue)
   int32_t* h_boxes = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -196,6 +197,8 @@ struct SpCall {
   int phase = 0;                      // 0: whole extractor; 1: enqueue the network only; 2: everything after it
   bool keep_desc_on_device = false;   // `desc` may be null: descriptors are consumed on the device (LightGlue)
   bool defer_desc_sync = false;       // descriptor read-back into pinned staging on stream2, no final synchronise
+  bool host_cull = false;             // single-level calls: candidate NMS + read-back are enqueued in phase 1, without the
+                                      // boxes; the dynamic-box cull (exact and idempotent at scale 1) runs on the host in phase 2
 };
 struct YoloCall {
   Context* ctx = nullptr;

@@ -115,6 +115,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   if (octave.size() < (size_t)B * cap) { octave.resize((size_t)B * cap); size.resize((size_t)B * cap); }
   SpCall sp_call;
   sp_call.ctx = c; sp_call.keep_desc_on_device = true; sp_call.phase = 1;
+  sp_call.host_cull = p->use_yolo && p->sp.nlevels == 1;
   int rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
                            octave.data(), size.data(), desc, cap, n_out, mono_index);
   if (rc) return rc;

@@ -213,7 +213,24 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
 
   const bool prof = e->profiling;
   const int phase = call.phase;
+  // candidate NMS per cell + compaction + read-back (counts and, optimistically, the first CAND_FAST candidates of
+  // every frame in the same stream pass: one sync instead of two; frames with more get a second copy below)
+  auto enqueue_candidates = [&](const int32_t* d_boxes, const int32_t* d_box_offsets) -> int {
+    for (int l = 0; l < NL; l++) {
+      Context::Level& L = c->lv[l];
+      const int PH = (L.H / 8) * 8, PW = (L.W / 8) * 8, ncells = (int)L.cells.size();
+      if (ncells > 0) {
+        launch_cell_nms(L.prob, PH, PW, B, L.d_cells, ncells, p->ini_th, p->min_th, d_boxes, d_box_offsets,
+                        19 - 3, scales[l], L.slot_xyr, L.slot_count, L.slot_stride, s);
+        launch_cell_compact(L.slot_xyr, L.slot_count, ncells, L.slot_stride, B, L.cand, L.cand_count, CAND_CAP, s);
+        HIP_TRY(e, hipMemcpyAsync(L.h_cand_count, L.cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpy2DAsync(L.h_cand, (size_t)CAND_CAP * 12, L.cand, (size_t)CAND_CAP * 12, (size_t)CAND_FAST * 12, B, hipMemcpyDeviceToHost, s));
+      }
+    }
+    return 0;
+  };
   if (phase != 2) {
+    c->cands_enqueued = false;
     // ---- inputs
     const uint8_t* dimg = imgs;
     const size_t fbytes = (size_t)H * stride;
@@ -249,12 +266,18 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, s);
     }
     HIP_TRY(e, hipGetLastError());
-    if (phase == 1) return DANI_OK;   // network enqueued; the caller continues with phase 2 once the boxes are known
+    if (phase == 1) {   // network enqueued; the caller continues with phase 2 once the boxes are known
+      if (call.host_cull && NL == 1) {   // scale 1: the cull is an exact filter, so the candidates need not wait for the boxes
+        if ((rc = enqueue_candidates(nullptr, nullptr))) return rc;
+        c->cands_enqueued = true;
+      }
+      return DANI_OK;
+    }
   }
   int nboxes_total = 0;
   if (boxes && box_offsets) nboxes_total = box_offsets[B];
   if (nboxes_total > c->box_cap) return fail(e, DANI_ERR_INVALID, "too many dynamic boxes (%d)", nboxes_total);
-  {
+  if (!c->cands_enqueued) {
     int32_t* hb = c->h_boxes;
     if (nboxes_total) memcpy(hb, boxes, (size_t)nboxes_total * 16);
     int32_t* ho = hb + c->box_cap * 4;
@@ -262,19 +285,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     if (nboxes_total) HIP_TRY(e, hipMemcpyAsync(c->d_boxes, hb, (size_t)nboxes_total * 16, hipMemcpyHostToDevice, s));
     HIP_TRY(e, hipMemcpyAsync(c->d_box_offsets, ho, (size_t)(B + 1) * 4, hipMemcpyHostToDevice, s));
   }
-  for (int l = 0; l < NL; l++) {
-    Context::Level& L = c->lv[l];
-    const int PH = (L.H / 8) * 8, PW = (L.W / 8) * 8, ncells = (int)L.cells.size();
-    if (ncells > 0) {
-      launch_cell_nms(L.prob, PH, PW, B, L.d_cells, ncells, p->ini_th, p->min_th, c->d_boxes, c->d_box_offsets,
-                      19 - 3, scales[l], L.slot_xyr, L.slot_count, L.slot_stride, s);
-      launch_cell_compact(L.slot_xyr, L.slot_count, ncells, L.slot_stride, B, L.cand, L.cand_count, CAND_CAP, s);
-      HIP_TRY(e, hipMemcpyAsync(L.h_cand_count, L.cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-      // optimistic read-back of the first CAND_FAST candidates of every frame in the same stream pass (one sync
-      // instead of two); frames with more candidates get a second copy below
-      HIP_TRY(e, hipMemcpy2DAsync(L.h_cand, (size_t)CAND_CAP * 12, L.cand, (size_t)CAND_CAP * 12, (size_t)CAND_FAST * 12, B, hipMemcpyDeviceToHost, s));
-    }
-  }
+  if (!c->cands_enqueued && (rc = enqueue_candidates(c->d_boxes, c->d_box_offsets))) return rc;
   HIP_TRY(e, hipEventRecord(c->ev[2], s));
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipStreamSynchronize(s));
@@ -302,9 +313,26 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
   host_pool().run(B * NL, [&](int t) {
     const int b = t / NL, l = t % NL;
     const Context::Level& L = c->lv[l];
-    const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+    HostKey* keys = reinterpret_cast<HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+    if (c->cands_enqueued && boxes && box_offsets && box_offsets[b + 1] > box_offsets[b]) {
+      // dynamic-box cull of SPextractor.cpp:314-352 at scale 1: (p + border) tested with Rect::contains (left / top
+      // inclusive, right / bottom exclusive, saturate_cast<int> = round half to even); the round trip is exact, so one
+      // pass over the finished list equals the reference's pass after every cell.  Order is preserved.
+      int m = 0;
+      for (int i = 0; i < L.h_cand_count[b]; i++) {
+        const int px = (int)lrintf(keys[i].x + (float)minBorderX), py = (int)lrintf(keys[i].y + (float)minBorderY);
+        bool inside = false;
+        for (int bi = box_offsets[b]; bi < box_offsets[b + 1] && !inside; bi++) {
+          const int32_t* r = boxes + 4 * bi;
+          inside = r[0] <= px && px < r[0] + r[2] && r[1] <= py && py < r[1] + r[3];
+        }
+        if (!inside) keys[m++] = keys[i];
+      }
+      L.h_cand_count[b] = m;
+    }
     distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[l], sels[t]);
   });
+  c->cands_enqueued = false;
   for (int b = 0; b < B; b++) {
     int n = 0;
     for (int l = 0; l < NL; l++) n += (int)sels[(size_t)b * NL + l].size();
