@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/dani_frontend.h"
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -134,12 +135,22 @@ class HostPool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
+  // Wake the workers ahead of a run() that is known to come within a few hundred microseconds (the caller is about to
+  // block on a stream synchronise whose completion starts the host stage): a sleeping worker takes 30-60 us to get
+  // going, long enough for the caller to have run several of the 8 per-frame tasks itself.  Awake workers poll for
+  // `spin_us` and go back to sleep if nothing arrives.
+  void prewake(int spin_us = 400) {
+    spin_until_.store(now_ns() + (int64_t)spin_us * 1000, std::memory_order_relaxed);
+    { std::lock_guard<std::mutex> lk(m_); wake_epoch_++; }
+    cv_.notify_all();
+  }
   // runs fn(0..count-1); the caller takes part; returns when all are done
   void run(int count, const std::function<void(int)>& fn) {
     if (count <= 1 || th_.empty()) { for (int i = 0; i < count; i++) fn(i); return; }
     {
       std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; count_ = count; next_ = 0; remaining_ = count; gen_++;
+      fn_ = &fn; count_ = count; next_ = 0; remaining_ = count;
+      gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
     work();
@@ -149,6 +160,9 @@ class HostPool {
   }
 
  private:
+  static int64_t now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
   void work() {
     for (;;) {
       int i;
@@ -166,14 +180,20 @@ class HostPool {
     }
   }
   void loop() {
-    uint64_t seen = 0;
+    uint64_t seen = 0, seen_wake = 0;
     for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-        if (stop_) return;
-        seen = gen_;
+      // awake: poll for a job until the prewake deadline passes
+      while (gen_.load(std::memory_order_acquire) == seen && now_ns() < spin_until_.load(std::memory_order_relaxed)) {
+        for (int k = 0; k < 64; k++) __builtin_ia32_pause();
       }
+      if (gen_.load(std::memory_order_acquire) == seen) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_.load(std::memory_order_acquire) != seen || wake_epoch_ != seen_wake; });
+        if (stop_) return;
+        seen_wake = wake_epoch_;
+        if (gen_.load(std::memory_order_acquire) == seen) continue;   // pre-woken: go and poll
+      }
+      seen = gen_.load(std::memory_order_acquire);
       work();
     }
   }
@@ -182,7 +202,9 @@ class HostPool {
   std::condition_variable cv_, done_;
   const std::function<void(int)>* fn_ = nullptr;
   int count_ = 0, next_ = 0, remaining_ = 0;
-  uint64_t gen_ = 0;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<int64_t> spin_until_{0};
+  uint64_t wake_epoch_ = 0;
   bool stop_ = false;
 };
 

@@ -288,6 +288,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
   if (!c->cands_enqueued && (rc = enqueue_candidates(c->d_boxes, c->d_box_offsets))) return rc;
   HIP_TRY(e, hipEventRecord(c->ev[2], s));
   HIP_TRY(e, hipGetLastError());
+  host_pool().prewake();   // the quadtree tasks start as soon as this synchronise returns
   HIP_TRY(e, hipStreamSynchronize(s));
   bool more = false;
   for (int l = 0; l < NL; l++) {
