@@ -305,41 +305,41 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
   }
   if (more) HIP_TRY(e, hipStreamSynchronize(s));
 
-  // ---- host: quadtree per (frame, level), keypoint assembly (SPextractor.cpp:359-376, :164-216)
+  // ---- host: quadtree per (frame, level) + keypoint assembly (SPextractor.cpp:359-376, :164-216), frames in parallel
   const auto t0 = std::chrono::steady_clock::now();
   const int minBorderX = 19 - 3, minBorderY = minBorderX;
   int32_t* h_lv = reinterpret_cast<int32_t*>(c->h_kxy + (size_t)MB * c->kcap * 2);   // [level][0: offset, 1: count][MB]
-  int status = DANI_OK;
-  std::vector<std::vector<int>> sels((size_t)B * NL);
-  host_pool().run(B * NL, [&](int t) {
-    const int b = t / NL, l = t % NL;
-    const Context::Level& L = c->lv[l];
-    HostKey* keys = reinterpret_cast<HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
-    if (c->cands_enqueued && boxes && box_offsets && box_offsets[b + 1] > box_offsets[b]) {
-      // dynamic-box cull of SPextractor.cpp:314-352 at scale 1: (p + border) tested with Rect::contains (left / top
-      // inclusive, right / bottom exclusive, saturate_cast<int> = round half to even); the round trip is exact, so one
-      // pass over the finished list equals the reference's pass after every cell.  Order is preserved.
-      int m = 0;
-      for (int i = 0; i < L.h_cand_count[b]; i++) {
-        const int px = (int)lrintf(keys[i].x + (float)minBorderX), py = (int)lrintf(keys[i].y + (float)minBorderY);
-        bool inside = false;
-        for (int bi = box_offsets[b]; bi < box_offsets[b + 1] && !inside; bi++) {
-          const int32_t* r = boxes + 4 * bi;
-          inside = r[0] <= px && px < r[0] + r[2] && r[1] <= py && py < r[1] + r[3];
+  std::vector<int> frame_status(B, DANI_OK);
+  const bool host_cull = c->cands_enqueued;
+  // one task per frame: (cull,) quadtree of every level, then the keypoint assembly of that frame
+  host_pool().run(B, [&](int b) {
+    std::vector<std::vector<int>> sels(NL);
+    for (int l = 0; l < NL; l++) {
+      const Context::Level& L = c->lv[l];
+      HostKey* keys = reinterpret_cast<HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+      if (host_cull && boxes && box_offsets && box_offsets[b + 1] > box_offsets[b]) {
+        // dynamic-box cull of SPextractor.cpp:314-352 at scale 1: (p + border) tested with Rect::contains (left / top
+        // inclusive, right / bottom exclusive, saturate_cast<int> = round half to even); the round trip is exact, so
+        // one pass over the finished list equals the reference's pass after every cell.  Order is preserved.
+        int m = 0;
+        for (int i = 0; i < L.h_cand_count[b]; i++) {
+          const int px = (int)lrintf(keys[i].x + (float)minBorderX), py = (int)lrintf(keys[i].y + (float)minBorderY);
+          bool inside = false;
+          for (int bi = box_offsets[b]; bi < box_offsets[b + 1] && !inside; bi++) {
+            const int32_t* r = boxes + 4 * bi;
+            inside = r[0] <= px && px < r[0] + r[2] && r[1] <= py && py < r[1] + r[3];
+          }
+          if (!inside) keys[m++] = keys[i];
         }
-        if (!inside) keys[m++] = keys[i];
+        L.h_cand_count[b] = m;
       }
-      L.h_cand_count[b] = m;
+      distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[l], sels[l]);
     }
-    distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[l], sels[t]);
-  });
-  c->cands_enqueued = false;
-  for (int b = 0; b < B; b++) {
     int n = 0;
-    for (int l = 0; l < NL; l++) n += (int)sels[(size_t)b * NL + l].size();
+    for (int l = 0; l < NL; l++) n += (int)sels[l].size();
     n_out[b] = n;
     const bool fits = n <= cap && n <= c->kcap;
-    if (!fits) status = DANI_ERR_CAPACITY;
+    if (!fits) frame_status[b] = DANI_ERR_CAPACITY;
     float* kx = c->h_kxy + (size_t)b * c->kcap * 2;
     float* ok = kpts_xy + (size_t)b * cap * 2;
     float* orr = resp + (size_t)b * cap;
@@ -350,7 +350,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     for (int l = 0; l < NL; l++) {
       const Context::Level& L = c->lv[l];
       const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
-      const std::vector<int>& sel = sels[(size_t)b * NL + l];
+      const std::vector<int>& sel = sels[l];
       const int nl = fits ? (int)sel.size() : 0;
       h_lv[(l * 2 + 0) * MB + b] = off;
       h_lv[(l * 2 + 1) * MB + b] = nl;
@@ -367,7 +367,10 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       off += nl;
     }
     if (mono_index) mono_index[b] = monoIndex;
-  }
+  });
+  c->cands_enqueued = false;
+  int status = DANI_OK;
+  for (int b = 0; b < B; b++) if (frame_status[b] != DANI_OK) status = frame_status[b];
   c->ms[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (status != DANI_OK) return fail(e, status, "output capacity %d too small", cap);
 
