@@ -75,8 +75,8 @@ def cpu_baseline(gray, bgr, weights):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
                     help="frames per GPU per step (default 8 = BASELINE config #4's 64 frames / 8 GPUs)")
@@ -170,12 +170,21 @@ def main():
         torch.cuda.synchronize()
     reduce_dev = dev if backend == "nccl" else None
 
+    # settle phase (untimed, part of set-up): first touches of every workspace, clocks and the host worker pool reach steady
+    # state; a process that starts right after another one released the GPU sees a few slow steps
+    run_steps(30, False)
     run_steps(max(args.warmup, NSEQ), False)
+    # like timeit: no cyclic-GC pass inside the timed region (a generation-2 collection over the weight / frame objects
+    # of this process takes 35-50 ms, four steps' worth, and lands ~0.7 s after start-up)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     outs, layer_ms, fe_ms, attn, lin = run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     eng.set_profiling(False)
     out = next(o for o in outs if o is not None)
 
