@@ -274,6 +274,40 @@ int dani_desc_best2(dani_engine* e, const float* q_desc, int32_t nq, const float
                    best_level2, nullptr);
 }
 
+int dani_desc_mean(dani_engine* e, const float* rows, int32_t nrows, const int32_t* offsets, const int32_t* row_idx, int32_t nq,
+                   float* mean_out) {
+  if (!e) return DANI_ERR_INVALID;
+  if (nq < 0 || nrows < 0 || (nq && (!offsets || !mean_out))) return fail(e, DANI_ERR_INVALID, "bad dani_desc_mean argument");
+  if (nq == 0) return DANI_OK;
+  const int total = offsets[nq];
+  if (total < 0 || (total && (!row_idx || !rows))) return fail(e, DANI_ERR_INVALID, "bad observation lists");
+  for (int i = 0; i < total; i++)
+    if (row_idx[i] < 0 || row_idx[i] >= nrows) return fail(e, DANI_ERR_INVALID, "row index %d outside [0, %d)", row_idx[i], nrows);
+  HIP_TRY(e, hipSetDevice(e->device));
+  CtxLease lease(e, nullptr);
+  Context* c = lease.c;
+  if (!c) return fail(e, DANI_ERR_INVALID, "all contexts busy");
+  hipStream_t s = c->stream;
+  const size_t br = (size_t)std::max(nrows, 1) * 1024, bo = (size_t)(nq + 1) * 4, bi = (size_t)std::max(total, 1) * 4, bout = (size_t)nq * 1024;
+  const size_t need = br + bo + bi + bout;
+  if (need > c->scan_ws_bytes) {
+    if (c->scan_ws) (void)hipFree(c->scan_ws);
+    c->scan_ws = nullptr; c->scan_ws_bytes = 0;
+    HIP_TRY(e, hipMalloc((void**)&c->scan_ws, need + need / 4));
+    c->scan_ws_bytes = need + need / 4;
+  }
+  char* d = c->scan_ws;
+  float* dr = (float*)d; int32_t* doff = (int32_t*)(d + br); int32_t* di = (int32_t*)(d + br + bo); float* dout = (float*)(d + br + bo + bi);
+  if (nrows) HIP_TRY(e, hipMemcpyAsync(dr, rows, (size_t)nrows * 1024, hipMemcpyHostToDevice, s));
+  HIP_TRY(e, hipMemcpyAsync(doff, offsets, bo, hipMemcpyHostToDevice, s));
+  if (total) HIP_TRY(e, hipMemcpyAsync(di, row_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
+  launch_desc_mean(dr, doff, di, nq, dout, s);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(mean_out, dout, bout, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  return DANI_OK;
+}
+
 int dani_desc_scan(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt,
                    const int32_t* t_level, const int32_t* cand_offsets, const int32_t* cand_idx,
                    float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,

@@ -458,4 +458,35 @@ void launch_desc_best2(const float* q, const float* t, const int32_t* t_level, c
                        best_idx, best_level, best_level2, cand_dist);
 }
 
+// ---------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors (/root/reference/src/MapPoint.cc:330-379) for many map
+// points at once: mean of the observing keyframes' descriptor rows, accumulated in f32 in list order (cv::Mat += per
+// row, then /= (float)count) -> bit-identical to the host loop.  One wavefront per map point, 4 channels per lane, four
+// rows in flight (HBM / L2 gather, 1 KiB per row).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void desc_mean_kernel(const float* rows, const int32_t* off, const int32_t* idx, int nq, float* out) {
+  const int qi = blockIdx.x, lane = threadIdx.x;
+  if (qi >= nq) return;
+  const int c0 = off[qi], c1 = off[qi + 1];
+  float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  int c = c0;
+  for (; c + 4 <= c1; c += 4) {
+    float4 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) b[u] = reinterpret_cast<const float4*>(rows + (size_t)idx[c + u] * 256)[lane];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { acc.x += b[u].x; acc.y += b[u].y; acc.z += b[u].z; acc.w += b[u].w; }
+  }
+  for (; c < c1; c++) {
+    const float4 b = reinterpret_cast<const float4*>(rows + (size_t)idx[c] * 256)[lane];
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+  }
+  if (c1 > c0) { const float n = (float)(c1 - c0); acc.x /= n; acc.y /= n; acc.z /= n; acc.w /= n; }
+  reinterpret_cast<float4*>(out + (size_t)qi * 256)[lane] = acc;
+}
+
+void launch_desc_mean(const float* rows, const int32_t* off, const int32_t* idx, int nq, float* out, hipStream_t s) {
+  if (nq > 0) hipLaunchKernelGGL(desc_mean_kernel, dim3(nq), dim3(64), 0, s, rows, off, idx, nq, out);
+}
+
 }  // namespace dani

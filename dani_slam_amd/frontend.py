@@ -85,6 +85,7 @@ def load_library():
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_lg_attention_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
+    lib.dani_desc_mean.argtypes = [C.c_void_p, _f, C.c_int32, _i32, _i32, C.c_int32, _f]
     lib.dani_desc_scan.argtypes = [C.c_void_p, _f, C.c_int32, _f, C.c_int32, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _f]
     lib.dani_lg_linear_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
     lib.dani_lg_debug_fetch.argtypes = [C.c_void_p, C.c_int32, _f, _i32, _f, C.c_int32]
@@ -480,6 +481,17 @@ class Engine:
         self._check(self.lib.dani_desc_scan(self.h, _fp(q), nq, _fp(t), nt, _ip(lvl) if lvl is not None else None, _ip(offs), _ip(idx),
                                             _fp(bd), _fp(bd2), _ip(bi), _ip(bl), _ip(bl2), _fp(cd)))
         return (bd, bd2, bi, bl, bl2), [cd[offs[i]:offs[i + 1]] for i in range(nq)]
+
+    def desc_mean(self, rows, obs_lists):
+        """MapPoint::ComputeDistinctiveDescriptors for many map points (src/MapPoint.cc:330-379): mean of rows[obs] in list order."""
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, 256)
+        nq = len(obs_lists)
+        offs = np.zeros(nq + 1, np.int32)
+        offs[1:] = np.cumsum([len(o) for o in obs_lists])
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(o, np.int32) for o in obs_lists]) if offs[nq] else np.zeros(1, np.int32), np.int32)
+        out = np.empty((max(nq, 1), 256), np.float32)
+        self._check(self.lib.dani_desc_mean(self.h, _fp(rows), len(rows), _ip(offs), _ip(idx), nq, _fp(out)))
+        return out[:nq]
 
     def set_profiling(self, on=True):
         self._check(self.lib.dani_set_profiling(self.h, int(on)))

@@ -259,6 +259,13 @@ DANI_API int dani_desc_scan(dani_engine* e, const float* q_desc, int32_t nq, con
                             float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
                             int32_t* best_level2, float* cand_dist);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:330-379) for nq map points at
+ * once: mean_out[q] = (sum of rows[row_idx[c]] for c in [offsets[q], offsets[q+1]), accumulated in f32 in list order)
+ * / (float)count -- the reference's cv::Mat += / /= sequence; a map point with no observation gets zeros.  rows is the
+ * pool of observing keyframes' descriptor rows [nrows][256]; all pointers are HOST pointers. */
+DANI_API int dani_desc_mean(dani_engine* e, const float* rows, int32_t nrows, const int32_t* offsets, const int32_t* row_idx,
+                            int32_t nq, float* mean_out);
+
 /* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
 
 /* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.

@@ -63,3 +63,14 @@ def search_by_projection(q_desc, t_desc, t_level, cand_lists, nn_ratio=0.8, clai
             claimed[bi] = True
             matches.append((qi, bi))
     return matches
+
+
+def distinctive_descriptor(rows, obs):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:330-379): meanDescriptor = zeros; += every observation's
+    descriptor row in order (f32); /= (float)count.  None when there is no observation (the reference returns early)."""
+    if len(obs) == 0:
+        return None
+    acc = np.zeros(256, np.float32)
+    for i in obs:
+        acc = (acc + np.asarray(rows[i], np.float32)).astype(np.float32)
+    return (acc / np.float32(len(obs))).astype(np.float32)

@@ -98,3 +98,22 @@ def test_projection_search_pipeline(sp_weights):
     good = sum(1 for qi, ki in ref if gt[qi] == ki)
     assert good > 0.9 * len(ref) and len(ref) > 500
     e.close()
+
+
+def test_distinctive_descriptors_match_oracle(sp_weights):
+    """SURVEY 8(f) rank 4: batched MapPoint::ComputeDistinctiveDescriptors, bit-identical to the sequential f32 host loop."""
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, weights=sp_weights)
+    rng = np.random.RandomState(4)
+    rows = rng.standard_normal((3000, 256)).astype(np.float32)
+    obs = [rng.randint(0, len(rows), int(rng.choice([0, 1, 2, 3, 4, 5, 9, 40]))).tolist() for _ in range(500)]
+    got = e.desc_mean(rows, obs)
+    for q, o in enumerate(obs):
+        ref = mo.distinctive_descriptor(rows, o)
+        if ref is None:
+            assert not got[q].any()
+        else:
+            assert np.array_equal(got[q], ref), q
+    with pytest.raises(frontend.DaniError):
+        e.desc_mean(rows, [[len(rows)]])
+    e.close()
