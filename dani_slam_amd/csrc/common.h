@@ -118,6 +118,8 @@ void launch_resize_u8c1(const uint8_t* src, int B, int sw, int sh, int sstride, 
                         hipStream_t s);
 void launch_copy_layer_dense(const ActDesc& a, int b, float* out_dense, hipStream_t s);
 // L2 descriptor distance + best / second-best scan over candidate lists (CSR)
+void launch_bow_descend(const float* feats, int n, const int32_t* child_off, const int32_t* child_ids, const float* node_desc,
+                        int nid_level, int32_t* leaf_out, int32_t* nid_out, hipStream_t s);
 void launch_desc_mean(const float* rows, const int32_t* off, const int32_t* idx, int nq, float* out, hipStream_t s);
 void launch_desc_best2(const float* q, const float* t, const int32_t* t_level, const int32_t* cand_off,
                        const int32_t* cand_idx, int nq, float* best_dist, float* best_dist2, int32_t* best_idx,

@@ -1,6 +1,8 @@
 // frontend_engine.cpp -- the fused per-frame front-end (sequence mode) and the projection-search descriptor scans.
 #include "engine_internal.h"
 
+#include <cmath>
+
 using namespace dani;
 using namespace dani::eng;
 
@@ -315,6 +317,117 @@ int dani_desc_scan(dani_engine* e, const float* q_desc, int32_t nq, const float*
   if (!cand_dist && nq > 0 && cand_offsets && cand_offsets[nq] > 0) return fail(e, DANI_ERR_INVALID, "dani_desc_scan needs cand_dist");
   return desc_scan(e, q_desc, nq, t_desc, nt, t_level, cand_offsets, cand_idx, best_dist, best_dist2, best_idx, best_level,
                    best_level2, cand_dist);
+}
+
+
+/* ---- DBoW3 transform of float descriptors ---------------------------------------------------- */
+
+struct dani_vocab {
+  dani_engine* e = nullptr;
+  int n_nodes = 0, L = 0;
+  int32_t* d_child_off = nullptr; int32_t* d_child_ids = nullptr; float* d_desc = nullptr;
+  std::vector<int32_t> child_off;      // host copies of what the host half of the transform needs
+  std::vector<double> weight;
+  std::vector<int32_t> word_id;
+  float* d_feats = nullptr; int32_t* d_out = nullptr; int cap = 0;   // per-call staging, grow-only
+  std::mutex mu;
+};
+
+int dani_vocab_create(dani_engine* e, int32_t n_nodes, int32_t L, const int32_t* child_offsets, const int32_t* child_ids,
+                      const float* node_desc, const double* node_weight, const int32_t* node_word_id, dani_vocab** out) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!out || n_nodes < 1 || L < 1 || !child_offsets || !child_ids || !node_desc || !node_weight || !node_word_id)
+    return fail(e, DANI_ERR_INVALID, "bad dani_vocab_create argument");
+  const int nchild = child_offsets[n_nodes];
+  if (child_offsets[0] != 0 || nchild < 0 || nchild > n_nodes) return fail(e, DANI_ERR_INVALID, "bad child lists");
+  for (int i = 0; i < n_nodes; i++) if (child_offsets[i + 1] < child_offsets[i]) return fail(e, DANI_ERR_INVALID, "child offsets not monotone");
+  for (int i = 0; i < nchild; i++) if (child_ids[i] <= 0 || child_ids[i] >= n_nodes) return fail(e, DANI_ERR_INVALID, "child id %d outside (0, %d)", child_ids[i], n_nodes);
+  // every descent must terminate: a child id larger than its parent's is what DBoW3's builder produces (nodes are
+  // appended as they are created); require it, so that no input can make the kernel loop for ever
+  for (int p = 0; p < n_nodes; p++)
+    for (int c = child_offsets[p]; c < child_offsets[p + 1]; c++)
+      if (child_ids[c] <= p) return fail(e, DANI_ERR_INVALID, "node %d has child %d: ids must grow down the tree", p, child_ids[c]);
+  HIP_TRY(e, hipSetDevice(e->device));
+  dani_vocab* v = new dani_vocab();
+  v->e = e; v->n_nodes = n_nodes; v->L = L;
+  v->child_off.assign(child_offsets, child_offsets + n_nodes + 1);
+  v->weight.assign(node_weight, node_weight + n_nodes);
+  v->word_id.assign(node_word_id, node_word_id + n_nodes);
+  if (hipMalloc((void**)&v->d_child_off, (size_t)(n_nodes + 1) * 4) != hipSuccess || hipMalloc((void**)&v->d_child_ids, (size_t)std::max(nchild, 1) * 4) != hipSuccess ||
+      hipMalloc((void**)&v->d_desc, (size_t)n_nodes * 1024) != hipSuccess) { dani_vocab_destroy(v); return fail(e, DANI_ERR_HIP, "hipMalloc failed (vocabulary)"); }
+  HIP_TRY(e, hipMemcpy(v->d_child_off, child_offsets, (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice));
+  if (nchild) HIP_TRY(e, hipMemcpy(v->d_child_ids, child_ids, (size_t)nchild * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(v->d_desc, node_desc, (size_t)n_nodes * 1024, hipMemcpyHostToDevice));
+  *out = v;
+  return DANI_OK;
+}
+
+void dani_vocab_destroy(dani_vocab* v) {
+  if (!v) return;
+  if (v->e) (void)hipSetDevice(v->e->device);
+  for (void* p : {(void*)v->d_child_off, (void*)v->d_child_ids, (void*)v->d_desc, (void*)v->d_feats, (void*)v->d_out}) if (p) (void)hipFree(p);
+  delete v;
+}
+
+int dani_bow_transform(dani_engine* e, dani_vocab* v, const float* feats, int32_t n, int32_t levelsup, int32_t weighting, int32_t norm,
+                       int32_t* word_ids, double* word_values, int32_t* n_words, int32_t* fv_node_ids, int32_t* fv_offsets,
+                       int32_t* fv_features, int32_t* n_fv_nodes) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!v || v->e != e || n < 0 || (n && !feats) || weighting < 0 || weighting > 3 || norm < 0 || norm > 2 || !word_ids || !word_values || !n_words ||
+      !fv_node_ids || !fv_offsets || !fv_features || !n_fv_nodes) return fail(e, DANI_ERR_INVALID, "bad dani_bow_transform argument");
+  *n_words = 0; *n_fv_nodes = 0; fv_offsets[0] = 0;
+  if (n == 0) return DANI_OK;
+  std::lock_guard<std::mutex> lk(v->mu);
+  HIP_TRY(e, hipSetDevice(e->device));
+  CtxLease lease(e, nullptr);
+  Context* c = lease.c;
+  if (!c) return fail(e, DANI_ERR_INVALID, "all contexts busy");
+  hipStream_t s = c->stream;
+  if (n > v->cap) {
+    if (v->d_feats) (void)hipFree(v->d_feats);
+    if (v->d_out) (void)hipFree(v->d_out);
+    v->d_feats = nullptr; v->d_out = nullptr; v->cap = 0;
+    HIP_TRY(e, hipMalloc((void**)&v->d_feats, (size_t)n * 1024));
+    HIP_TRY(e, hipMalloc((void**)&v->d_out, (size_t)n * 8));
+    v->cap = n;
+  }
+  HIP_TRY(e, hipMemcpyAsync(v->d_feats, feats, (size_t)n * 1024, hipMemcpyHostToDevice, s));
+  launch_bow_descend(v->d_feats, n, v->d_child_off, v->d_child_ids, v->d_desc, v->L - levelsup, v->d_out, v->d_out + n, s);
+  HIP_TRY(e, hipGetLastError());
+  std::vector<int32_t> leaf_nid((size_t)2 * n);
+  HIP_TRY(e, hipMemcpyAsync(leaf_nid.data(), v->d_out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  // BowVector / FeatureVector bookkeeping in feature order (Vocabulary.cpp:752-824, BowVector.cpp:34-84,
+  // FeatureVector.cpp:31-45): std::map semantics, double weights
+  std::map<int32_t, double> bow;
+  std::map<int32_t, std::vector<int32_t>> fv;
+  const bool tf = weighting <= 1;   // 0 TF_IDF, 1 TF: addWeight; 2 IDF, 3 BINARY: addIfNotExist
+  for (int i = 0; i < n; i++) {
+    const int leaf = leaf_nid[i], nid = leaf_nid[n + i];
+    const double w = v->weight[leaf];
+    if (!(w > 0)) continue;            // stopped word
+    const int32_t wid = v->word_id[leaf];
+    if (tf) bow[wid] += w; else bow.emplace(wid, w);
+    fv[nid].push_back(i);
+  }
+  if (tf && !bow.empty() && norm == 0) { const double nd = (double)bow.size(); for (auto& kv : bow) kv.second /= nd; }
+  if (norm != 0) {
+    double nn = 0.0;
+    if (norm == 1) for (auto& kv : bow) nn += std::fabs(kv.second);
+    else { for (auto& kv : bow) nn += kv.second * kv.second; nn = std::sqrt(nn); }
+    if (nn > 0.0) for (auto& kv : bow) kv.second /= nn;
+  }
+  int k = 0;
+  for (auto& kv : bow) { word_ids[k] = kv.first; word_values[k] = kv.second; k++; }
+  *n_words = k;
+  int m = 0, off = 0;
+  for (auto& kv : fv) {
+    fv_node_ids[m] = kv.first;
+    for (int32_t fi : kv.second) fv_features[off++] = fi;
+    fv_offsets[++m] = off;
+  }
+  *n_fv_nodes = m;
+  return DANI_OK;
 }
 
 }  // extern "C"

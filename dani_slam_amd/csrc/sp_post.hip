@@ -489,4 +489,45 @@ void launch_desc_mean(const float* rows, const int32_t* off, const int32_t* idx,
   if (nq > 0) hipLaunchKernelGGL(desc_mean_kernel, dim3(nq), dim3(64), 0, s, rows, off, idx, nq, out);
 }
 
+// ---------------------------------------------------------------------------------------------
+// the tree descent of DBoW3's Vocabulary::transform for float descriptors
+// (/root/reference/Thirdparty/DBow3/src/Vocabulary.cpp:836-873, called through Frame::ComputeBoW, src/Frame.cc:740-747).
+// One wavefront per feature: at every level the squared L2 distance to each child -- DescManip::distance,
+// DescManip.cpp:120-129: float difference, float product, double accumulation -- is formed 4 dimensions per lane and
+// reduced over the wave; children are visited in stored order with strict `<`.  (The double sum of 256 float products is
+// exact unless their magnitudes span more than ~2^29, so the tree-shaped reduction equals the reference's sequential
+// one; a last-bit difference could only flip a decision between two children that tie to 1 ulp of a double.)
+// Outputs per feature: the leaf node reached and the ancestor at level `nid_level` (0 = root when nid_level <= 0).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void bow_descend_kernel(const float* feats, int n, const int32_t* child_off, const int32_t* child_ids,
+                                                         const float* node_desc, int nid_level, int32_t* leaf_out, int32_t* nid_out) {
+  const int f = blockIdx.x, lane = threadIdx.x;
+  if (f >= n) return;
+  const float4 a = reinterpret_cast<const float4*>(feats + (size_t)f * 256)[lane];
+  int node = 0, level = 0, nid = 0;
+  for (;;) {
+    const int c0 = child_off[node], c1 = child_off[node + 1];
+    if (c1 <= c0) break;                       // leaf
+    ++level;
+    double best = 1.7976931348623157e308;
+    int best_id = child_ids[c0];
+    for (int c = c0; c < c1; c++) {
+      const int id = child_ids[c];
+      const float4 b = reinterpret_cast<const float4*>(node_desc + (size_t)id * 256)[lane];
+      const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+      const float p0 = d0 * d0, p1 = d1 * d1, p2 = d2 * d2, p3 = d3 * d3;
+      const double sd = wave_sum_f64((((double)p0 + (double)p1) + (double)p2) + (double)p3);
+      if (sd < best) { best = sd; best_id = id; }
+    }
+    node = best_id;
+    if (level == nid_level) nid = node;
+  }
+  if (lane == 0) { leaf_out[f] = node; nid_out[f] = nid; }
+}
+
+void launch_bow_descend(const float* feats, int n, const int32_t* child_off, const int32_t* child_ids, const float* node_desc,
+                        int nid_level, int32_t* leaf_out, int32_t* nid_out, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(bow_descend_kernel, dim3(n), dim3(64), 0, s, feats, n, child_off, child_ids, node_desc, nid_level, leaf_out, nid_out);
+}
+
 }  // namespace dani

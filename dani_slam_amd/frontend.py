@@ -85,6 +85,10 @@ def load_library():
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_lg_attention_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
+    lib.dani_vocab_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32, _i32, _f, C.POINTER(C.c_double), _i32, C.POINTER(C.c_void_p)]
+    lib.dani_vocab_destroy.argtypes = [C.c_void_p]
+    lib.dani_vocab_destroy.restype = None
+    lib.dani_bow_transform.argtypes = [C.c_void_p, C.c_void_p, _f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32, C.POINTER(C.c_double), _i32, _i32, _i32, _i32, _i32]
     lib.dani_desc_mean.argtypes = [C.c_void_p, _f, C.c_int32, _i32, _i32, C.c_int32, _f]
     lib.dani_desc_scan.argtypes = [C.c_void_p, _f, C.c_int32, _f, C.c_int32, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32, _f]
     lib.dani_lg_linear_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
@@ -492,6 +496,33 @@ class Engine:
         out = np.empty((max(nq, 1), 256), np.float32)
         self._check(self.lib.dani_desc_mean(self.h, _fp(rows), len(rows), _ip(offs), _ip(idx), nq, _fp(out)))
         return out[:nq]
+
+    # -- DBoW3 transform -----------------------------------------------------------
+    def vocab_create(self, L, child_offsets, child_ids, node_desc, node_weight, node_word_id):
+        """A DBoW3 vocabulary tree on the device (dani_vocab_create); returns an opaque handle for bow_transform / vocab_destroy."""
+        co = np.ascontiguousarray(child_offsets, np.int32); ci = np.ascontiguousarray(child_ids, np.int32)
+        nd = np.ascontiguousarray(node_desc, np.float32).reshape(-1, 256)
+        nw = np.ascontiguousarray(node_weight, np.float64); wi = np.ascontiguousarray(node_word_id, np.int32)
+        h = C.c_void_p()
+        self._check(self.lib.dani_vocab_create(self.h, len(nd), int(L), _ip(co), _ip(ci), _fp(nd), nw.ctypes.data_as(C.POINTER(C.c_double)),
+                                               _ip(wi), C.byref(h)))
+        return h
+
+    def vocab_destroy(self, vocab):
+        self.lib.dani_vocab_destroy(vocab)
+
+    def bow_transform(self, vocab, feats, levelsup=4, weighting=0, norm=1):
+        """Vocabulary::transform(features, BowVector, FeatureVector, levelsup): returns (bow dict word -> value,
+        feature-vector dict node -> list of feature indices), both in ascending key order."""
+        f = np.ascontiguousarray(feats, np.float32).reshape(-1, 256)
+        n = len(f)
+        wid = np.zeros(max(n, 1), np.int32); wv = np.zeros(max(n, 1), np.float64); nw = C.c_int32(0)
+        fn = np.zeros(max(n, 1), np.int32); fo = np.zeros(n + 1, np.int32); ff = np.zeros(max(n, 1), np.int32); nf = C.c_int32(0)
+        self._check(self.lib.dani_bow_transform(self.h, vocab, _fp(f), n, levelsup, weighting, norm, _ip(wid), wv.ctypes.data_as(C.POINTER(C.c_double)),
+                                                C.byref(nw), _ip(fn), _ip(fo), _ip(ff), C.byref(nf)))
+        bow = {int(wid[i]): float(wv[i]) for i in range(nw.value)}
+        fv = {int(fn[i]): ff[fo[i]:fo[i + 1]].tolist() for i in range(nf.value)}
+        return bow, fv
 
     def set_profiling(self, on=True):
         self._check(self.lib.dani_set_profiling(self.h, int(on)))

@@ -266,6 +266,28 @@ DANI_API int dani_desc_scan(dani_engine* e, const float* q_desc, int32_t nq, con
 DANI_API int dani_desc_mean(dani_engine* e, const float* rows, int32_t nrows, const int32_t* offsets, const int32_t* row_idx,
                             int32_t nq, float* mean_out);
 
+/* ---- DBoW3 transform of float descriptors ------------------------- */
+
+/* A DBoW3 vocabulary tree resident on the device.  Node 0 is the root; node i's children are
+ * child_ids[child_offsets[i] .. child_offsets[i+1]) in DBoW3's stored order (a leaf has none; child ids are larger than
+ * their parent's, as DBoW3's builder produces them); node_desc [n_nodes][256] f32 (the root's row is unused),
+ * node_weight / node_word_id as Vocabulary::Node::weight / word_id (Thirdparty/DBow3/src/Vocabulary.h:311-342).  L =
+ * depth levels (Vocabulary::m_L).  The reference loads the tree with Vocabulary::load; the SuperPoint vocabulary itself
+ * is withheld upstream, so only synthetic trees have been through this path. */
+typedef struct dani_vocab dani_vocab;
+DANI_API int dani_vocab_create(dani_engine* e, int32_t n_nodes, int32_t L, const int32_t* child_offsets, const int32_t* child_ids,
+                               const float* node_desc, const double* node_weight, const int32_t* node_word_id, dani_vocab** out);
+DANI_API void dani_vocab_destroy(dani_vocab* v);
+/* Vocabulary::transform(features, BowVector&, FeatureVector&, levelsup) (Vocabulary.cpp:752-824; called with levelsup = 4
+ * by Frame::ComputeBoW, src/Frame.cc:740-747).  The per-feature tree descent (squared-L2 distances to every child,
+ * DescManip.cpp:120-129) runs on the GPU; the std::map bookkeeping, in feature order and in double, on the host.
+ * weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (Vocabulary::m_weighting); norm: 0 none, 1 L1, 2 L2 (the scoring object's
+ * mustNormalize).  Outputs: BowVector as word ids in ascending order + values (capacity n); FeatureVector as node ids in
+ * ascending order + CSR lists of feature indices (fv_offsets capacity n + 1). */
+DANI_API int dani_bow_transform(dani_engine* e, dani_vocab* v, const float* feats, int32_t n, int32_t levelsup, int32_t weighting,
+                                int32_t norm, int32_t* word_ids, double* word_values, int32_t* n_words, int32_t* fv_node_ids,
+                                int32_t* fv_offsets, int32_t* fv_features, int32_t* n_fv_nodes);
+
 /* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
 
 /* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.

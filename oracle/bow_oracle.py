@@ -1,0 +1,104 @@
+"""oracle/bow_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement of DBoW3's transform of float descriptors, as Frame::ComputeBoW uses it
+(/root/reference/src/Frame.cc:740-747 -> Vocabulary::transform(features, BowVector&, FeatureVector&, levelsup = 4)):
+    Vocabulary::transform (tree descent)     Thirdparty/DBow3/src/Vocabulary.cpp:836-873
+    Vocabulary::transform (bookkeeping)      Vocabulary.cpp:752-824
+    DescManip::distance (CV_32F branch)      DescManip.cpp:120-129   float difference, float product, double accumulation
+    BowVector::addWeight / addIfNotExist / normalize    BowVector.cpp:34-84
+    FeatureVector::addFeature                FeatureVector.cpp:31-45
+DBoW3 is vendored in the reference tree (Thirdparty/DBow3), but the SuperPoint vocabulary file is withheld upstream
+ and the library needs OpenCV to build: PARITY UNPINNED by any reference fixture; literal restatement of the
+cited lines on synthetic trees.  Only tests/ may import this module.
+"""
+import math
+
+import numpy as np
+
+
+def make_tree(seed, k=10, L=3, dim=256, stop_fraction=0.05):
+    """A synthetic k-ary vocabulary of depth L in DBoW3's node order (children appended as their parent is expanded,
+    breadth first): returns dict(child_offsets, child_ids, desc, weight, word_id, L)."""
+    rng = np.random.default_rng(seed)
+    children = [[]]
+    desc = [np.zeros(dim, np.float32)]
+    level = [0]
+    frontier = [0]
+    for lv in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            kk = k if rng.random() > 0.1 else max(2, k // 2)        # some nodes have fewer children
+            for _ in range(kk):
+                nid = len(children)
+                children.append([]); level.append(lv)
+                desc.append((desc[p] + rng.standard_normal(dim).astype(np.float32) * np.float32(1.0 / lv)).astype(np.float32))
+                children[p].append(nid); nxt.append(nid)
+        frontier = nxt
+    n = len(children)
+    weight = np.zeros(n, np.float64); word_id = np.zeros(n, np.int32)
+    w = 0
+    for i in range(n):
+        if not children[i]:
+            word_id[i] = w; w += 1
+            weight[i] = 0.0 if rng.random() < stop_fraction else float(rng.uniform(0.1, 8.0))     # idf; 0 = stopped word
+    offs = np.zeros(n + 1, np.int32)
+    offs[1:] = np.cumsum([len(c) for c in children])
+    ids = np.array([c for ch in children for c in ch], np.int32)
+    return dict(child_offsets=offs, child_ids=ids, desc=np.stack(desc), weight=weight, word_id=word_id, L=L)
+
+
+def distance(a, b):
+    d = (np.asarray(a, np.float32) - np.asarray(b, np.float32)).astype(np.float32)
+    p = (d * d).astype(np.float32)                       # float product
+    return float(np.cumsum(p.astype(np.float64))[-1])    # sequential double accumulation (cumsum is sequential)
+
+
+def descend(tree, feature, levelsup):
+    offs, ids, desc = tree["child_offsets"], tree["child_ids"], tree["desc"]
+    nid_level = tree["L"] - levelsup
+    nid = 0
+    node, level = 0, 0
+    while offs[node + 1] > offs[node]:
+        level += 1
+        best, best_id = float("inf"), None
+        for c in ids[offs[node]:offs[node + 1]]:
+            d = distance(feature, desc[c])
+            if d < best:
+                best, best_id = d, int(c)
+        node = best_id
+        if level == nid_level:
+            nid = node
+    return node, nid
+
+
+def transform(tree, feats, levelsup=4, weighting=0, norm=1):
+    """Returns (bow: dict word -> value in ascending key order, fv: dict node -> feature indices)."""
+    bow, fv = {}, {}
+    tf = weighting <= 1
+    for i, f in enumerate(np.asarray(feats, np.float32).reshape(-1, 256)):
+        leaf, nid = descend(tree, f, levelsup)
+        w = float(tree["weight"][leaf])
+        if not w > 0:
+            continue
+        wid = int(tree["word_id"][leaf])
+        if tf:
+            bow[wid] = bow.get(wid, 0.0) + w
+        elif wid not in bow:
+            bow[wid] = w
+        fv.setdefault(nid, []).append(i)
+    bow = dict(sorted(bow.items())); fv = dict(sorted(fv.items()))
+    if tf and bow and norm == 0:
+        nd = float(len(bow))
+        bow = {k: v / nd for k, v in bow.items()}
+    if norm:
+        nn = 0.0
+        if norm == 1:
+            for v in bow.values():
+                nn += abs(v)
+        else:
+            for v in bow.values():
+                nn += v * v
+            nn = math.sqrt(nn)
+        if nn > 0:
+            bow = {k: v / nn for k, v in bow.items()}
+    return bow, fv
