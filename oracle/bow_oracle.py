@@ -16,37 +16,6 @@ import math
 import numpy as np
 
 
-def make_tree(seed, k=10, L=3, dim=256, stop_fraction=0.05):
-    """A synthetic k-ary vocabulary of depth L in DBoW3's node order (children appended as their parent is expanded,
-    breadth first): returns dict(child_offsets, child_ids, desc, weight, word_id, L)."""
-    rng = np.random.default_rng(seed)
-    children = [[]]
-    desc = [np.zeros(dim, np.float32)]
-    level = [0]
-    frontier = [0]
-    for lv in range(1, L + 1):
-        nxt = []
-        for p in frontier:
-            kk = k if rng.random() > 0.1 else max(2, k // 2)        # some nodes have fewer children
-            for _ in range(kk):
-                nid = len(children)
-                children.append([]); level.append(lv)
-                desc.append((desc[p] + rng.standard_normal(dim).astype(np.float32) * np.float32(1.0 / lv)).astype(np.float32))
-                children[p].append(nid); nxt.append(nid)
-        frontier = nxt
-    n = len(children)
-    weight = np.zeros(n, np.float64); word_id = np.zeros(n, np.int32)
-    w = 0
-    for i in range(n):
-        if not children[i]:
-            word_id[i] = w; w += 1
-            weight[i] = 0.0 if rng.random() < stop_fraction else float(rng.uniform(0.1, 8.0))     # idf; 0 = stopped word
-    offs = np.zeros(n + 1, np.int32)
-    offs[1:] = np.cumsum([len(c) for c in children])
-    ids = np.array([c for ch in children for c in ch], np.int32)
-    return dict(child_offsets=offs, child_ids=ids, desc=np.stack(desc), weight=weight, word_id=word_id, L=L)
-
-
 def distance(a, b):
     d = (np.asarray(a, np.float32) - np.asarray(b, np.float32)).astype(np.float32)
     p = (d * d).astype(np.float32)                       # float product

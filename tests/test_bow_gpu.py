@@ -4,6 +4,7 @@ SuperPoint vocabulary is withheld upstream)."""
 import numpy as np
 import pytest
 
+from dani_slam_amd import synth
 from oracle import bow_oracle as bo
 
 pytestmark = pytest.mark.gpu
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def test_transform_matches_oracle(sp_weights, k, L, levelsup, weighting, norm):
     from dani_slam_amd import frontend
     e = frontend.Engine(device=0, weights=sp_weights)
-    tree = bo.make_tree(7 + k + L, k=k, L=L)
+    tree = synth.vocab_tree(7 + k + L, k=k, L=L)
     rng = np.random.default_rng(3)
     leaves = np.nonzero(np.diff(tree["child_offsets"]) == 0)[0]
     # features near leaves (repeated words, incl. stopped ones) and far from everything
@@ -38,7 +39,7 @@ def test_transform_matches_oracle(sp_weights, k, L, levelsup, weighting, norm):
 def test_vocabulary_validation(sp_weights):
     from dani_slam_amd import frontend
     e = frontend.Engine(device=0, weights=sp_weights)
-    tree = bo.make_tree(1, k=3, L=2)
+    tree = synth.vocab_tree(1, k=3, L=2)
     bad = tree["child_ids"].copy(); bad[0] = 0                            # a child pointing back at the root: would never terminate
     with pytest.raises(frontend.DaniError):
         e.vocab_create(tree["L"], tree["child_offsets"], bad, tree["desc"], tree["weight"], tree["word_id"])
