@@ -12,12 +12,13 @@ struct LgSet { int tok_off, n, partner_off, partner_n; float size_w, size_h; con
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 constexpr int AT_STRIDE = 33;
 
-enum { F_XCD = 1, F_NOSOFTMAX = 2, F_NOSTAGE = 4, F_NOPV = 8, F_NOS = 16, F_NOBAR = 32, F_PRIO_SLOT = 64, F_PRIO_ODD = 128, F_PRIO_PHASE = 256, F_PRIO_PV = 512, F_PRIO_LOW1 = 1024, F_PIPE = 2048 };
+enum { F_XCD = 1, F_NOSOFTMAX = 2, F_NOSTAGE = 4, F_NOPV = 8, F_NOS = 16, F_NOBAR = 32, F_PRIO_SLOT = 64, F_PRIO_ODD = 128, F_PRIO_PHASE = 256, F_PRIO_PV = 512, F_PRIO_LOW1 = 1024, F_PIPE = 2048, F_DBUF = 4096 };
 
 template <int OCC, int FLAGS>
 __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
                                                               const LgSet* sets, int cross, float scale) {
-  __shared__ float sKV[4 * 64 * AT_STRIDE];
+  extern __shared__ float sKV_dyn[];
+  float* sKV = sKV_dyn;   // [2 buffers (F_DBUF)][key half][K | V][64 d][33]
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   {
     const int L0 = bx + gridDim.x * (by + gridDim.y * bz);
@@ -75,8 +76,32 @@ __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, co
       pf[u] = *reinterpret_cast<const f32x4*>(gsrc[u] + min(hsel[u] + (it_), ntiles - 1) * 32);    \
   }
   ATK_PREFETCH(0);
+  constexpr int BUF = 4 * 64 * AT_STRIDE;
+  if (FLAGS & F_DBUF) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) sKV[loff[u] + c] = pf[u][c];
+    }
+    __syncthreads();
+    if (1 < half) ATK_PREFETCH(1);
+  }
   for (int it = 0; it < half; it++) {
-    if (FLAGS & F_PRIO_PV) __builtin_amdgcn_s_setprio(0);
+    if (FLAGS & F_DBUF) {
+      // stage tile it + 1 into the other buffer (its registers arrived during the previous tile's compute), start the
+      // load of tile it + 2, then compute on tile it; ONE barrier per iteration
+      if (it + 1 < half) {
+        float* dst = sKV + ((it + 1) & 1) * BUF;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+          for (int c = 0; c < 4; c++) dst[loff[u] + c] = pf[u][c];
+        }
+        if (it + 2 < half) ATK_PREFETCH(it + 2);
+      }
+      sK = sKV + (it & 1) * BUF + (size_t)kh * 2 * 64 * AT_STRIDE;
+      sV = sK + 64 * AT_STRIDE;
+    } else
     if (!(FLAGS & F_NOSTAGE) || it == 0) {
       if (!(FLAGS & F_NOBAR)) __syncthreads();
 #pragma unroll
@@ -85,7 +110,7 @@ __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, co
         for (int c = 0; c < 4; c++) sKV[loff[u] + c] = pf[u][c];
       }
       if (!(FLAGS & F_NOBAR)) __syncthreads();
-      if (it + 1 < half) ATK_PREFETCH(it + 1);
+      if (!(FLAGS & 0) && it + 1 < half) ATK_PREFETCH(it + 1);
     }
     const int kt = kh * half + it;
     if (wave_active && kt < ntiles) {
@@ -163,6 +188,7 @@ __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, co
         for (int r = 0; r < 16; r++) { o[0][r] += s[r]; }
       }
     }
+    if (FLAGS & F_DBUF) __syncthreads();
   }
 #undef ATK_PREFETCH
   __syncthreads();
@@ -192,11 +218,10 @@ __global__ __launch_bounds__(256, OCC) void attn_probe_kernel(const float* Q, co
 }
 
 #define VARIANTS \
-  RUN(2, 0, "baseline") \
-  RUN(2, F_PIPE, "operand reads one group ahead") \
-  RUN(2, F_NOSTAGE | F_NOSOFTMAX, "MFMA + LDS reads only") \
-  RUN(2, F_NOSTAGE | F_NOSOFTMAX | F_PIPE, "MFMA + LDS reads only, reads ahead") \
-  RUN(2, 0, "baseline again")
+  RUN(2, F_PIPE, "reads ahead (product)") \
+  RUN(2, F_PIPE | F_DBUF, "reads ahead + double-buffered LDS, 1 barrier") \
+  RUN(1, F_PIPE | F_DBUF, "same, 1 WG / CU") \
+  RUN(2, F_PIPE, "reads ahead (product) again")
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -227,15 +252,16 @@ int main(int argc, char** argv) {
   std::vector<Variant> vs;
 #define RUN(occ, fl, nm) vs.push_back(Variant{nm, attn_probe_kernel<occ, fl>, occ, {}});
   VARIANTS
+  for (auto& v : vs) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 64 * AT_STRIDE * 4));
   hipEvent_t a, b;
   CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   dim3 grid((np + 63) / 64, 4, nsets);
   const int rounds = 7, reps = 10;
   for (int rd = 0; rd < rounds; rd++)
     for (auto& v : vs) {
-      hipLaunchKernelGGL(v.fn, grid, dim3(256), 0, 0, Q, K, V, O, ld, ds, 0, 0.125f);
+      hipLaunchKernelGGL(v.fn, grid, dim3(256), 2 * 4 * 64 * AT_STRIDE * 4, 0, Q, K, V, O, ld, ds, 0, 0.125f);
       CK(hipEventRecord(a, 0));
-      for (int i = 0; i < reps; i++) hipLaunchKernelGGL(v.fn, grid, dim3(256), 0, 0, Q, K, V, O, ld, ds, 0, 0.125f);
+      for (int i = 0; i < reps; i++) hipLaunchKernelGGL(v.fn, grid, dim3(256), 2 * 4 * 64 * AT_STRIDE * 4, 0, Q, K, V, O, ld, ds, 0, 0.125f);
       CK(hipEventRecord(b, 0));
       CK(hipEventSynchronize(b));
       float ms = 0;
