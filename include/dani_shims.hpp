@@ -1,8 +1,9 @@
 // dani_shims.hpp -- header-only C++17 shims that keep the reference's class names and method signatures on top
 // of the C ABI in dani_frontend.h.  They replace include/SPextractor.h (+ SuperPoint.h) of the reference; see
-// INTEGRATION.md.  This header needs OpenCV (cv::Mat, cv::KeyPoint) exactly like the headers it replaces and is
-// therefore compiled only inside the reference's build tree -- OpenCV is not present in this repo's image, so it
-// is NOT built or tested here (the Python mirror dani_slam_amd/frontend.py exercises the same ABI calls).
+// INTEGRATION.md.  This header needs OpenCV (cv::Mat, cv::KeyPoint) exactly like the headers it replaces.  OpenCV is not
+// present in this repo's image: here the header is compiled and run end to end against a mock of the few core types it
+// touches (tests/cpp/mock_opencv, tests/test_shims_gpu.py -- results identical to the ctypes path); against the real
+// library it is compiled inside the reference's build tree.
 #pragma once
 #include <opencv2/core/core.hpp>
 
