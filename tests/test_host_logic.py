@@ -113,3 +113,15 @@ def test_product_never_imports_the_oracle():
             continue
         src = open(os.path.join(pkg, "csrc", fn)).read()
         assert "#include \"../../oracle" not in src and "liboracle" not in src
+
+
+def test_shim_header_compiles_as_cxx17(tmp_path):
+    """include/dani_shims.hpp (the reference-facing C++ classes) must at least compile here: against the mock OpenCV
+    core types of tests/cpp/mock_opencv, since the real library is absent (run end to end in tests/test_shims_gpu.py)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if not cxx:
+        pytest.skip("no g++")
+    subprocess.check_call([cxx, "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "tests/cpp/mock_opencv"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests/cpp/shim_smoke.cpp")])
