@@ -125,7 +125,7 @@ def main():
 
     import threading
     NSEQ = max(1, args.sequences)
-    PROF_EVERY = 4
+    PROF_EVERY = 10
 
     def step(seq=0):
         if args.host_inputs:
