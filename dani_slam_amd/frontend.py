@@ -398,7 +398,7 @@ class Engine:
 
     def frontend_batch(self, gray, bgr=None, nfeatures=1024, iniTh=0.015, minTh=0.007, use_yolo=True, match_previous=True,
                        lg_threshold=0.05, lapping=(0, 0), want_desc=True, device_ptrs=None, shape=None, box_cap=512, copy=True,
-                       sequence=0):
+                       sequence=0, scaleFactor=1.2, nlevels=1):
         """gray [B,H,W] u8 and bgr [B,H,W,3] u8 host arrays, or device_ptrs=(gray_ptr, bgr_ptr) + shape=(B,H,W).
         Returns a list of per-frame dicts: kpts, resp, desc (or None), mono_index, boxes [k,4], matches [K,2], scores.
         copy=False returns views into buffers that the next call overwrites."""
@@ -419,7 +419,7 @@ class Engine:
             on_dev = 1
         cap = nfeatures + 8
         p = _FrontendParams()
-        p.sp = _SpParams(nfeatures, 1.2, 1, iniTh, minTh)
+        p.sp = _SpParams(nfeatures, scaleFactor, nlevels, iniTh, minTh)
         p.use_yolo = int(use_yolo); p.yolo_score_thresh = 0.4; p.yolo_iou_thresh = 0.5
         p.match_previous = int(match_previous); p.lg_threshold = lg_threshold
         p.lapping[0], p.lapping[1] = int(lapping[0]), int(lapping[1])

@@ -88,3 +88,21 @@ def test_capacity_errors_are_reported(weights):
     with pytest.raises(frontend.DaniError):
         e.frontend_batch(np.stack([gray[0]] * 3), np.stack([bgr[0]] * 3), nfeatures=NF)   # batch above max_batch
     e.close()
+
+
+def test_fused_call_with_a_pyramid(weights, sp_weights):
+    """nLevels > 1 through the fused call: the dynamic-box cull stays in the kernel (with its scale drift replay, quirk
+    Q6) instead of moving to the host as it does for single-level calls."""
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=2, weights=weights)
+    e.yolo_set_classes(yo.COCO_NAMES, yo.DYNAMIC_NAMES)
+    gray = np.stack([synth.frame(1), synth.frame(4)]); bgr = np.stack([synth.frame_bgr(1), synth.frame_bgr(4)])
+    out = e.frontend_batch(gray, bgr, nfeatures=600, nlevels=3, scaleFactor=1.2)
+    for i in range(2):
+        ok, dets, dyn, dmap = yo.detect(weights, bgr[i])
+        assert [tuple(int(v) for v in r) for r in out[i]["boxes"]] == [tuple(r) for r in dyn] and len(dyn) >= 1
+        ref = oracle.sp_extract(gray[i], sp_weights, nfeatures=600, nlevels=3, scaleFactor=1.2, boxes=dyn)
+        assert np.array_equal(out[i]["kpts"], ref["kpts"])
+        assert np.array_equal(out[i]["desc"], ref["desc"])
+    assert len(out[1]["matches"]) >= 0
+    e.close()
