@@ -106,3 +106,21 @@ def test_fused_call_with_a_pyramid(weights, sp_weights):
         assert np.array_equal(out[i]["desc"], ref["desc"])
     assert len(out[1]["matches"]) >= 0
     e.close()
+
+
+def test_sequences_keep_their_own_predecessor(weights):
+    """Two cameras interleaved on one engine: each `sequence` id matches against its own previous frame."""
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=1, weights=weights)
+    e.yolo_set_classes(yo.COCO_NAMES, yo.DYNAMIC_NAMES)
+    f = lambda i: (synth.frame(i)[None], synth.frame_bgr(i)[None])
+    a0 = e.frontend_batch(*f(0), nfeatures=NF, sequence=0)[0]
+    b0 = e.frontend_batch(*f(3), nfeatures=NF, sequence=1)[0]
+    assert len(a0["matches"]) == 0 and len(b0["matches"]) == 0          # no predecessor yet in either sequence
+    a1 = e.frontend_batch(*f(0), nfeatures=NF, sequence=0)[0]           # the same frame again: identity matches
+    b1 = e.frontend_batch(*f(3), nfeatures=NF, sequence=1)[0]
+    for r in (a1, b1):
+        assert len(r["matches"]) > 100 and np.all(r["matches"][:, 0] == r["matches"][:, 1])
+    c = e.frontend_batch(*f(3), nfeatures=NF, sequence=0)[0]            # frame 3 against sequence 0's frame 0: not identity
+    assert not (len(c["matches"]) > 100 and np.all(c["matches"][:, 0] == c["matches"][:, 1]))
+    e.close()
