@@ -57,13 +57,15 @@ def _check_pair(engine, w, k0, d0, k1, d1, size0=SIZE, size1=SIZE, thr=0.05):
     return m, s, mo, so
 
 
-@pytest.mark.parametrize("n0,n1", [(1024, 1024), (128, 128), (7, 7), (1025, 1000), (33, 700), (1025, 1025), (40, 1030), (64, 70), (1027, 1028), (35, 36)])
+@pytest.mark.parametrize("n0,n1", [(1024, 1024), (128, 128), (7, 7), (1025, 1000), (33, 700), (1025, 1025), (40, 1030), (64, 70), (1027, 1028), (35, 36), (2049, 1999)])
 def test_pair_matches_oracle(engine, lg_weights, n0, n1):
     k0, d0, k1, d1, gt = synth.matching_pair(n0 + n1, n0=n0, n1=n1)
     m, s, mo, so = _check_pair(engine, lg_weights, k0, d0, k1, d1)
-    if min(n0, n1) >= 1000:
+    if 1000 <= min(n0, n1) <= 1100:                               # (denser sets crowd the synthetic head)
         assert len(m) > 0.5 * (gt >= 0).sum()                     # the synthetic head finds most true matches
         assert (gt[m[:, 0]] == m[:, 1]).mean() > 0.99
+    if min(n0, n1) > 1100:
+        assert len(m) > 100 and (gt[m[:, 0]] == m[:, 1]).mean() > 0.95
     assert np.all(np.diff(m[:, 0]) > 0) if len(m) > 1 else True   # increasing queryIdx order
 
 
