@@ -39,8 +39,9 @@ __device__ __forceinline__ float wave_sumf(float v) {
 
 // ---------------------------------------------------------------------------------------------
 // linear_fm_kernel:  Y[o][t] = epilogue( sum_k W[o][k] * X[k][t] + b[o] ),  X = concat(X0 rows, X1 rows).
-// Workgroup tile 64 outputs x 256 tokens; wave w owns tokens [64w, 64w+64) x 64 outputs = 2x2 accumulators.
-// K is streamed in chunks of 32 rows through LDS with register prefetch (same pipeline as conv_mfma_kernel).
+// Workgroup tile 64 outputs x TT tokens (TT = 64 is what launch_linear_fm ships; the larger tiles stay for the tuning
+// hook g_lin_force_tt).  K is streamed through LDS in chunks of KC rows with register prefetch (same pipeline as
+// conv_mfma_kernel).
 // Epilogues: rotary embedding on rows < rot_rows (Wqkv with rows pre-permuted to [q|k|v][head][d]),
 //            scale alpha, residual add.
 // ---------------------------------------------------------------------------------------------
