@@ -142,6 +142,13 @@ struct LgSet {
   float size_w, size_h;
   const float* kp; const float* desc;
 };
+// bf16x3 variant (lg_x3.hip): same function and layout, contraction on the bf16 matrix cores at f32 accuracy.  w_x3 is
+// the weight split by pack_linear_x3 (x3_packed_u16(out, in) 16-bit words); OUT, K0, K1 multiples of 64.
+void launch_linear_x3(const float* x0, int K0, const float* x1, int K1, const void* w_x3, const float* bias_packed,
+                      float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
+                      int rot_rows, float alpha, hipStream_t s);
+size_t x3_packed_u16(int out, int in);
+void pack_linear_x3(const float* w_row_major, int out, int in, uint16_t* dst);
 void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s);

@@ -12,7 +12,7 @@ namespace eng {
 
 constexpr int LG_LAYERS = 9;
 
-struct LgLinear { float* w = nullptr; float* b = nullptr; int out = 0, in = 0; };
+struct LgLinear { float* w = nullptr; float* b = nullptr; void* w3 = nullptr; int out = 0, in = 0; };   // w3: bf16x3 split of w (lg_x3.hip)
 struct LgBlockW { LgLinear a, b, c, ffn0, ffn3; float* ln_g = nullptr; float* ln_b = nullptr; };  // self: a=Wqkv,b=out_proj; cross: a=to_qk,b=to_v,c=to_out
 struct LgWeights {
   bool ready = false;
@@ -85,7 +85,14 @@ int lg_pack_raw(dani_engine* e, const std::vector<float>& w, const std::vector<f
   L->out = out; L->in = in;
   int rc;
   if ((rc = lg_upload(e, wp, &L->w))) return rc;
-  return lg_upload(e, bp, &L->b);
+  if ((rc = lg_upload(e, bp, &L->b))) return rc;
+  // the same weight split into three bf16 terms, for the DANI_LG_GEMM_BF16X3 option
+  std::vector<uint16_t> w3(x3_packed_u16(out, in));
+  pack_linear_x3(w.data(), out, in, w3.data());
+  HIP_TRY(e, hipMalloc(&L->w3, w3.size() * 2));
+  e->weight_allocs.push_back(L->w3);
+  HIP_TRY(e, hipMemcpy(L->w3, w3.data(), w3.size() * 2, hipMemcpyHostToDevice));
+  return 0;
 }
 
 int lg_get_linear(dani_engine* e, const std::string& name, int out, int in, std::vector<float>& w, std::vector<float>& b) {
@@ -218,6 +225,7 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
   pairs = std::max(pairs, L->pairs); kmax = std::max(kmax, L->kmax);
   const int np = round_up(kmax, 32);
   const int ld = round_up(pairs * 2 * np + round_up(pairs * 2 * LG_TAIL_MAX, 32) + 128, 256);   // main regions + shared tail region
+  if ((size_t)768 * ld >= ((size_t)1 << 30)) return fail(e, DANI_ERR_INVALID, "LightGlue batch too large: %d token columns", ld);
   int rc;
 #define LGA(ptr, rows) if ((rc = lg_dev(e, L, (void**)&(ptr), (size_t)(rows) * ld * 4))) return rc;
   LGA(L->x, 256) LGA(L->qkv, 768) LGA(L->ctx, 256) LGA(L->msg, 256) LGA(L->hbuf, 512) LGA(L->qk, 256) LGA(L->v, 256)
@@ -240,7 +248,7 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
 // the 9-layer forward + assignment statistics on stream s; the sets in L->d_sets point at their token-major inputs
 struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T; };   // T = all main regions + the tail region
 
-void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof) {
+void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof, int gemm) {
   const int ld = L->ld, nsets = sh.nsets, max_n = sh.max_n, T = sh.T, max_np = round_up(max_n, 32);
   if (prof && !L->aev_ready) {
     for (auto& ev : L->aev) (void)hipEventCreate(&ev);
@@ -257,7 +265,8 @@ void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
   launch_posenc(L->d_sets, nsets, sh.max_span, W->wr, L->cosb, L->sinb, ld, s);
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
-    launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
+    if (gemm == DANI_LG_GEMM_BF16X3) launch_linear_x3(x0, K0, x1, K1, l.w3, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
+    else launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
   };
   for (int i = 0; i < LG_LAYERS; i++) {
@@ -296,6 +305,13 @@ LgContext* last_lg(dani_engine* e) {
 }  // namespace dani
 
 extern "C" {
+
+int dani_lg_set_gemm(dani_engine* e, int32_t mode) {
+  if (!e) return DANI_ERR_INVALID;
+  if (mode != DANI_LG_GEMM_F32 && mode != DANI_LG_GEMM_BF16X3) return fail(e, DANI_ERR_INVALID, "unknown LightGlue GEMM mode %d", mode);
+  e->lg_gemm = mode;
+  return DANI_OK;
+}
 
 }  // extern "C"
 
@@ -393,7 +409,7 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
   HIP_TRY(e, hipMemcpyAsync(L->d_sets, L->h_sets, sizeof(LgSet) * 2 * P, hipMemcpyHostToDevice, s));
   HIP_TRY(e, hipEventRecord(c->ev_lg0, s));
   const bool prof = e->profiling;
-  if (max_n > 0) lg_forward(W, L, sh, s, prof);
+  if (max_n > 0) lg_forward(W, L, sh, s, prof, e->lg_gemm);
   HIP_TRY(e, hipEventRecord(c->ev_lg1, s));
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemcpy2DAsync(L->h_m0, (size_t)L->ld * 4, L->m0, (size_t)L->ld * 4, (size_t)doff * 4, 3, hipMemcpyDeviceToHost, s));

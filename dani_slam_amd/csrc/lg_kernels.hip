@@ -19,6 +19,9 @@
 // for, and with whole-block padding that single keypoint cost every launch a third, almost empty round of workgroups
 // (1088 instead of 1024 on 512 slots: attention 193 us instead of 150 us per launch at 16 x 1025 keypoints).
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include "lin_epilogue.h"
 
 namespace dani {
 
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[KC * TT + KC * LIN_NCO];
   float* sX = lds;
   float* sW = lds + KC * TT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, and known to be: row bases go to the scalar unit
   // 1-D grid, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All output
   // tiles of one token tile go to the same XCD, back to back, so that the X tile they share is fetched into one L2
   // once instead of into all eight.
@@ -164,34 +168,13 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
     for (int r = 0; r < 16; r++) acc[0][0][r] += acc2[r];
   }
 
+  LinEpi ep;
+  ep.y = a.y; ep.res = a.res; ep.cosb = a.cosb; ep.sinb = a.sinb; ep.bias = nullptr; ep.ld = a.ld; ep.rot_rows = a.rot_rows; ep.alpha = a.alpha;
 #pragma unroll
   for (int tb = 0; tb < NTB; tb++) {
     const int tok = tok0 + wtok + tb * 32 + j;
-    const bool ok = tok < a.T;
 #pragma unroll
-    for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const int row = ot * LIN_NCO + wout + cb * 32 + acc_row(r, h);   // even; row+1 is register r+1
-        float v0 = acc[cb][tb][r], v1 = acc[cb][tb][r + 1];
-        if (row < a.rot_rows && ok) {
-          const int ip = (row & 63) >> 1;
-          const float c = a.cosb[(size_t)ip * a.ld + tok], s = a.sinb[(size_t)ip * a.ld + tok];
-          const float r0 = v0 * c - v1 * s, r1 = v1 * c + v0 * s;   // t*cos + rotate_half(t)*sin
-          v0 = r0; v1 = r1;
-        }
-        v0 *= a.alpha; v1 *= a.alpha;
-        if (ok && row < a.OUT) {
-          const size_t o0 = (size_t)row * a.ld + tok;
-          if (a.res) { v0 += a.res[o0]; }
-          a.y[o0] = v0;
-        }
-        if (ok && row + 1 < a.OUT) {
-          const size_t o1 = (size_t)(row + 1) * a.ld + tok;
-          if (a.res) { v1 += a.res[o1]; }
-          a.y[o1] = v1;
-        }
-      }
+    for (int cb = 0; cb < NCB; cb++) lin_epilogue<false>(acc[cb][tb], ot * LIN_NCO + wout + cb * 32, h, tok, tok < a.T, ep);
   }
 }
 
@@ -200,6 +183,10 @@ int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force th
 void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s) {
+  if (OUT % 64 || rot_rows % 64 || (size_t)OUT * ld >= ((size_t)1 << 30)) {   // contract of lin_epilogue.h
+    fprintf(stderr, "launch_linear_fm: unsupported shape OUT=%d rot_rows=%d ld=%d\n", OUT, rot_rows, ld);
+    abort();
+  }
   LinArgs a;
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w_packed; a.bias = bias_packed; a.y = y; a.res = res;
   a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;

@@ -75,6 +75,7 @@ def load_library():
     lib.dani_load_weights_file.argtypes = [C.c_void_p, C.c_char_p]
     lib.dani_finalize_weights.argtypes = [C.c_void_p]
     lib.dani_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    lib.dani_lg_set_gemm.argtypes = [C.c_void_p, C.c_int32]
     lib.dani_layer_timings.argtypes = [C.c_void_p, _f]
     lib.dani_last_timings.argtypes = [C.c_void_p, _f, C.c_int32]
     lib.dani_sp_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -523,6 +524,12 @@ class Engine:
         bow = {int(wid[i]): float(wv[i]) for i in range(nw.value)}
         fv = {int(fn[i]): ff[fo[i]:fo[i + 1]].tolist() for i in range(nf.value)}
         return bow, fv
+
+    LG_GEMM_F32, LG_GEMM_BF16X3 = 0, 1
+
+    def lg_set_gemm(self, mode):
+        """Arithmetic of LightGlue's linear layers: LG_GEMM_F32 (default, canonical order) or LG_GEMM_BF16X3."""
+        self._check(self.lib.dani_lg_set_gemm(self.h, int(mode)))
 
     def set_profiling(self, on=True):
         self._check(self.lib.dani_set_profiling(self.h, int(on)))
