@@ -91,6 +91,7 @@ def main():
                     help="arithmetic of LightGlue's linear layers for the TIMED region (dani_lg_set_gemm): f32 = f32 MFMA in the "
                          "oracle's canonical order (default, the headline); bf16x3 = three-term bf16 operand split, f32-accurate. "
                          "A default run also reports the bf16x3 mode in `lg_gemm_bf16x3`, measured after the timed region")
+    ap.add_argument("--no-side-modes", action="store_true", help="skip the extra lg_gemm_bf16x3 measurement (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -195,7 +196,7 @@ def main():
 
     # outside the timed region: the same workload with LightGlue's linear layers in the other arithmetic
     x3 = None
-    if args.lg_gemm == "f32" and world == 1 and NSEQ == 1:
+    if args.lg_gemm == "f32" and world == 1 and NSEQ == 1 and not args.no_side_modes:
         ref = [(np.array(o["matches"]).copy(), np.array(o["scores"]).copy()) for o in step()]   # f32 mode, same pairing as below
         eng.lg_set_gemm(eng.LG_GEMM_BF16X3)
         run_steps(10, False)

@@ -57,9 +57,9 @@ __device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsign
 }
 }  // namespace
 
-// NCB = 32-row output blocks per wave: 1 -> workgroup = 64 outputs x 64 tokens, 2 -> 128 outputs x 64 tokens (the split
-// of an X tile, its LDS traffic and its barriers are then shared by twice the outputs; used when OUT >= 512, where
-// the grid still has >= 8 workgroups per CU).
+// NCB = 32-row output blocks per wave: 1 -> workgroup = 64 outputs x 64 tokens (shipped), 2 -> 128 outputs x 64 tokens
+// (the split of an X tile, its LDS traffic and its barriers are shared by twice the outputs; measured slower, kept
+// behind the probe's tuning hook g_x3_force_ncb).
 template <int NCB>
 __global__ __launch_bounds__(256, NCB == 1 ? 4 : 3) void linear_x3_kernel(LinX3Args a) {
   constexpr int WG_OUT = 64 * NCB;
@@ -209,7 +209,8 @@ void launch_linear_x3(const float* x0, int K0, const float* x1, int K1, const vo
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = static_cast<const u32x4*>(w_x3); a.bias = bias_packed;
   a.y = y; a.res = res; a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;
   const int ntiles8 = ((T + X3_TT - 1) / X3_TT + 7) / 8 * 8;   // see the kernel: 8 XCDs
-  if (OUT % 128 == 0 && OUT >= 512 && g_x3_force_ncb != 1)
+  // the 64-output tile wins on every LightGlue shape (54 vs 57 us on Wqkv: the 128-output one runs at occupancy 3)
+  if (OUT % 128 == 0 && g_x3_force_ncb == 2)
     hipLaunchKernelGGL(linear_x3_kernel<2>, dim3((unsigned)(ntiles8 * (OUT / 128))), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL(linear_x3_kernel<1>, dim3((unsigned)(ntiles8 * ((OUT + 63) / 64))), dim3(256), 0, s, a);

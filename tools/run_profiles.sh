@@ -7,8 +7,8 @@
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_stats gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o s -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_stats.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc1 -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/pmc1.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc2 -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/pmc2.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc3 -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/pmc3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o s -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-side-modes > gpurun_out/prof_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc1 -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-side-modes > gpurun_out/pmc1.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc2 -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-side-modes > gpurun_out/pmc2.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc3 -o p -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-side-modes > gpurun_out/pmc3.log 2>&1
 ls gpurun_out/prof_stats gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3
