@@ -20,6 +20,8 @@
 // against L2, >1000 FLOP/B against HBM).
 #include "canon_math.h"
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace dani {
 
@@ -160,11 +162,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 
 #undef DANI_PREFETCH
   // ---- epilogue ----
-  const size_t oplane = (size_t)a.oHp * a.oWp;
+  // Addresses: an accumulator register's output channel is wave-uniform up to the lane half (cu + 4h), so the channel
+  // base goes to the scalar unit and the lane adds ONE 32-bit byte offset shared by all 16 x NCB registers.  Written per
+  // element as out[(size_t)co * oplane + (size_t)y * oWp + x] every store cost six 64-bit vector address instructions
+  // (203 of the 582 epilogue VALU instructions of the 3x3 kernel).  Per-frame tensors are < 2^32 bytes (launch_cfg).
+  const unsigned oplane = (unsigned)a.oHp * (unsigned)a.oWp;
   float* outb = a.out + (size_t)b * a.out_fs;
+  auto at_w = [](float* base, unsigned off) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off); };
+  auto at_r = [](const float* base, unsigned off) -> const float& { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); };
   if constexpr (C::POOL) {
     const int yo = (y0 + wave * 2) >> 1, xo = (x0 + j) >> 1;
     const bool ok = ((j & 1) == 0) && yo < (a.H >> 1) && xo < (a.W >> 1);
+    const unsigned lane_off = 4u * ((unsigned)(yo + a.opady) * (unsigned)a.oWp + (unsigned)(xo + PADX) + 4u * (unsigned)h * oplane);
 #pragma unroll
     for (int cb = 0; cb < C::NCB; cb++)
 #pragma unroll
@@ -172,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
         float m = fmaxf(acc[cb][0][r], acc[cb][1][r]);
         m = fmaxf(m, __shfl_xor(m, 1));
         if (C::ACT == ACT_RELU) m = m > 0.0f ? m : 0.0f;
-        const int co = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (ok && co < a.Cout) outb[(size_t)co * oplane + (size_t)(yo + a.opady) * a.oWp + xo + PADX] = m;
+        const int cu = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2);   // uniform; this lane's channel is cu + 4h
+        if (ok && cu + 4 * h < a.Cout) at_w(outb + (size_t)cu * oplane, lane_off) = m;
       }
   } else {
     const float* resb = a.res ? a.res + (size_t)b * a.res_fs : nullptr;
@@ -181,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     for (int pb = 0; pb < C::NPB; pb++) {
       const int y = y0 + wave * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
       const bool ok = y < a.H && x < a.W;
+      const unsigned lane_off = 4u * ((unsigned)(y + a.opady) * (unsigned)a.oWp + (unsigned)(x + PADX) + 4u * (unsigned)h * oplane);
 #pragma unroll
       for (int cb = 0; cb < C::NCB; cb++)
 #pragma unroll
@@ -188,11 +198,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
           float v = acc[cb][pb][r];
           if (C::ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
           if (C::ACT == ACT_SILU) v = v / (1.0f + dani_expf(-v));
-          const int co = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (ok && co < a.Cout) {
-            const size_t o = (size_t)co * oplane + (size_t)(y + a.opady) * a.oWp + x + PADX;
-            if (resb) v = resb[o] + v;
-            outb[o] = v;
+          const int cu = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2);   // uniform; this lane's channel is cu + 4h
+          if (ok && cu + 4 * h < a.Cout) {
+            const size_t cbase = (size_t)cu * oplane;
+            if (resb) v = at_r(resb + cbase, lane_off) + v;
+            at_w(outb + cbase, lane_off) = v;
           }
         }
     }
@@ -235,6 +245,10 @@ static void launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   a.tiles_y = (io.H + C::TH - 1) / C::TH;
   a.cout_tiles = L.cout_tiles;
   a.nchunks = L.CinPad / C::CC;
+  if ((size_t)(L.cout_tiles * C::NCO + 8) * io.oHp * io.oWp >= ((size_t)1 << 30)) {   // 32-bit byte offsets inside a frame (epilogue)
+    fprintf(stderr, "conv launch: output tensor of %d x %d x %d floats per frame is too large\n", L.Cout, io.oHp, io.oWp);
+    abort();
+  }
   const int grid = B * a.tiles_x * a.tiles_y * a.cout_tiles;
   hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), 0, s, a);
 }
