@@ -192,6 +192,7 @@ void assign_features_to_grid(const float* kxy, int n, float min_x, float min_y, 
 void features_in_area(const float* kxy, const int32_t* octave, float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
                       const int32_t* cell_offsets, const int32_t* cell_idx, float x, float y, float r, int min_level, int max_level,
                       std::vector<int32_t>& out);
+void undistort_keypoints(const float* xy, int n, const float K[4], const float* dist, int ndist, float* out);
 void stereo_from_matches(const float* ul_x, int nl, const float* ur_x, int nr, const int32_t* matches, const float* scores, int k,
                          float mb, float mbf, float* u_right, float* depth);
 void features_per_level(int nfeatures, float scaleFactor, int nlevels, std::vector<int>& per_level,

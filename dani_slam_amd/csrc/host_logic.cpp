@@ -408,6 +408,40 @@ void features_in_area(const float* kxy, const int32_t* octave, float min_x, floa
     }
 }
 
+// Frame::UndistortKeyPoints (src/Frame.cc:749-782): identity when the first distortion coefficient is exactly 0,
+// else cv::undistortPoints(pts, pts, K, distCoef, noArray(), K).  OpenCV is not part of the reference tree (find_package
+// OpenCV 4.2); this restates the published algorithm of its calib3d module for that call shape (R = identity, P = K,
+// default criteria = 5 fixed-point iterations): everything in double, inputs and outputs float.
+//   x = (u - cx) / fx, y = (v - cy) / fy;  five times:  r2 = x^2 + y^2,
+//   icdist = (1 + ((k6 r2 + k5) r2 + k4) r2) / (1 + ((k3 r2 + k2) r2 + k1) r2)   (k4..k6 = 0 here),
+//   dx = 2 p1 x y + p2 (r2 + 2 x^2),  dy = p1 (r2 + 2 y^2) + 2 p2 x y,  (x, y) = ((x0 - dx) icdist, (y0 - dy) icdist)
+//   (a negative icdist abandons the point at its normalised input);  out = (fx x + cx, fy y + cy).
+void undistort_keypoints(const float* xy, int n, const float K[4], const float* dist, int ndist, float* out) {
+  if (ndist < 1 || dist[0] == 0.0f) {
+    if (out != xy) memcpy(out, xy, (size_t)n * 8);
+    return;
+  }
+  double k[5] = {0, 0, 0, 0, 0};   // k1 k2 p1 p2 k3
+  for (int i = 0; i < ndist && i < 5; i++) k[i] = (double)dist[i];
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3], ifx = 1.0 / fx, ify = 1.0 / fy;
+  for (int i = 0; i < n; i++) {
+    double x = ((double)xy[2 * i] - cx) * ifx, y = ((double)xy[2 * i + 1] - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int it = 0; it < 5; it++) {
+      const double r2 = x * x + y * y;
+      const double icdist = 1.0 / (1.0 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) { x = x0; y = y0; break; }
+      const double dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+      const double dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+      x = (x0 - dx) * icdist;
+      y = (y0 - dy) * icdist;
+    }
+    const double xx = fx * x + cx, yy = fy * y + cy, ww = 1.0 / 1.0;   // P = K, third row (0 0 1)
+    out[2 * i] = (float)(xx * ww);
+    out[2 * i + 1] = (float)(yy * ww);
+  }
+}
+
 // Frame::ComputeStereoMatches after the LightGlue call (src/Frame.cc:862-914): disparity gate [0, mbf / mb), depth =
 // mbf / max-ish(disparity) (non-positive -> 0.01), then the matches whose (1 - score) reaches 1.5 x the median of the
 // sorted (distance, left index) pairs are cleared again.

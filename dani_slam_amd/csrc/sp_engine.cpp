@@ -527,6 +527,13 @@ int dani_host_stereo_from_matches(const float* ul_x, int32_t nl, const float* ur
   return DANI_OK;
 }
 
+int dani_host_undistort_keypoints(const float* kpts_xy, int32_t n, const float* K4, const float* dist, int32_t ndist, float* out_xy) {
+  if (n < 0 || !K4 || (n && (!kpts_xy || !out_xy)) || ndist < 0 || ndist > 5 || (ndist && !dist) || !(K4[0] != 0.0f) || !(K4[1] != 0.0f))
+    return DANI_ERR_INVALID;
+  undistort_keypoints(kpts_xy, n, K4, dist, ndist, out_xy);
+  return DANI_OK;
+}
+
 int dani_host_features_per_level(int32_t nfeatures, float scale_factor, int32_t nlevels, int32_t* per_level,
                                  float* scale_factors) {
   if (nlevels < 1 || !per_level) return DANI_ERR_INVALID;

@@ -187,6 +187,19 @@ def host_features_in_area(kxy, octave, grid_params, cell_offsets, cell_idx, qx, 
     return [idx[offs[i]:offs[i + 1]].copy() for i in range(nq)]
 
 
+def host_undistort_keypoints(kpts_xy, K4, dist):
+    """Frame::UndistortKeyPoints (src/Frame.cc:749-782): undistorted pixel coordinates [n, 2] float32."""
+    lib = load_library()
+    k = np.ascontiguousarray(kpts_xy, np.float32).reshape(-1, 2)
+    K = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist, np.float32)
+    out = np.empty((max(len(k), 1), 2), np.float32)
+    lib.dani_host_undistort_keypoints.argtypes = [_f, C.c_int32, _f, _f, C.c_int32, _f]
+    rc = lib.dani_host_undistort_keypoints(_fp(k) if len(k) else None, len(k), _fp(K), _fp(d) if len(d) else None, len(d), _fp(out))
+    if rc:
+        raise DaniError(rc, "dani_host_undistort_keypoints")
+    return out[:len(k)]
+
+
 def host_stereo_from_matches(ul_x, ur_x, matches, scores, mb, mbf):
     """Frame::ComputeStereoMatches post-filter (src/Frame.cc:862-914): returns (mvuRight, mvDepth)."""
     lib = load_library()

@@ -335,6 +335,13 @@ DANI_API int dani_host_features_in_area(const float* kpts_xy, const int32_t* oct
 DANI_API int dani_host_stereo_from_matches(const float* ul_x, int32_t nl, const float* ur_x, int32_t nr, const int32_t* matches,
                                            const float* scores, int32_t k, float mb, float mbf, float* u_right, float* depth);
 /* mnFeaturesPerLevel / mvScaleFactor tables (src/SPextractor.cpp:97-126). */
+/* Frame::UndistortKeyPoints (src/Frame.cc:749-782): mvKeysUn from mvKeys.  K4 = (fx, fy, cx, cy); dist = (k1, k2, p1, p2
+ * [, k3]) as in mDistCoef.  dist[0] == 0 (or ndist == 0) copies the input, as the reference does; otherwise the five
+ * fixed-point iterations of cv::undistortPoints(..., K, distCoef, noArray(), K) in double precision (OpenCV itself is an
+ * external dependency of the reference: restated from its published algorithm, see csrc/host_logic.cpp).  out_xy may
+ * alias kpts_xy. */
+DANI_API int dani_host_undistort_keypoints(const float* kpts_xy, int32_t n, const float* K4, const float* dist, int32_t ndist,
+                                           float* out_xy);
 DANI_API int dani_host_features_per_level(int32_t nfeatures, float scale_factor, int32_t nlevels, int32_t* per_level,
                                           float* scale_factors);
 

@@ -5,6 +5,8 @@ front-end:
     Frame::PosInGrid / AssignFeaturesToGrid      /root/reference/src/Frame.cc:727-737, 387-418   (Nleft == -1)
     Frame::GetFeaturesInArea                      src/Frame.cc:659-725
     Frame::ComputeStereoMatches (post-filter)     src/Frame.cc:862-914
+    Frame::UndistortKeyPoints                     src/Frame.cc:749-782  (cv::undistortPoints of OpenCV 4.2, an external
+                                                  dependency: restated from its published algorithm)
 PARITY UNPINNED by any reference fixture (none exist); literal restatements of the cited lines.  Only tests/ may import
 this module.
 """
@@ -62,6 +64,36 @@ def get_features_in_area(kxy, octave, grid, min_x, min_y, inv_w, inv_h, x, y, r,
                         continue
                 if abs(f32(kxy[k, 0] - x)) < r and abs(f32(kxy[k, 1] - y)) < r:
                     out.append(k)
+    return out
+
+
+def undistort_keypoints(kpts_xy, K4, dist):
+    """Frame::UndistortKeyPoints (/root/reference/src/Frame.cc:749-782).  The reference delegates to
+    cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK); OpenCV (4.2, found by the reference's CMake) is not in
+    the reference tree, so this follows the published algorithm of calib3d for R = I, P = K and the default five
+    iterations -- parity for this function is UNPINNED (no OpenCV here, no vectors in the reference)."""
+    k = np.asarray(kpts_xy, f32).reshape(-1, 2)
+    d = np.asarray(dist, f32)
+    if len(d) == 0 or d[0] == 0.0:
+        return k.copy()
+    c = np.zeros(5, np.float64); c[:min(len(d), 5)] = d[:5].astype(np.float64)
+    k1, k2, p1, p2, k3 = c
+    fx, fy, cx, cy = [np.float64(v) for v in np.asarray(K4, f32)]
+    ifx, ify = 1.0 / fx, 1.0 / fy
+    out = np.empty_like(k)
+    for i in range(len(k)):
+        x = (np.float64(k[i, 0]) - cx) * ifx; y = (np.float64(k[i, 1]) - cy) * ify
+        x0, y0 = x, y
+        for _ in range(5):
+            r2 = x * x + y * y
+            icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2)
+            if icdist < 0:
+                x, y = x0, y0
+                break
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x = (x0 - dx) * icdist; y = (y0 - dy) * icdist
+        out[i, 0] = f32(fx * x + cx); out[i, 1] = f32(fy * y + cy)
     return out
 
 

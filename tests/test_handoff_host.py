@@ -2,6 +2,7 @@
 dani_host_features_in_area, dani_host_stereo_from_matches) against oracle/handoff_oracle.py (literal Python restatement of
 src/Frame.cc:387-418, 659-737, 862-914)."""
 import numpy as np
+import pytest
 
 from dani_slam_amd import frontend
 from oracle import handoff_oracle as ho
@@ -70,3 +71,52 @@ def test_stereo_from_matches_matches_oracle():
         assert np.array_equal(u, ru) and np.array_equal(d, rd), k
         if k == 200:
             assert (d > 0).sum() > 20 and (d[il[1]] == -1) and (u[il[1]] == -1)
+
+
+# ---- Frame::UndistortKeyPoints (src/Frame.cc:749-782) ----------------------------------------------------------------
+TUM1_K = (517.306408, 516.469215, 318.643040, 255.313989)
+TUM1_DIST = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)      # the reference's Examples/RGB-D/TUM1.yaml camera
+
+
+def _distort(xy_un, K4, dist):
+    """Forward radial-tangential model (what undistortion inverts), float64."""
+    fx, fy, cx, cy = K4
+    k1, k2, p1, p2, k3 = (list(dist) + [0.0] * 5)[:5]
+    x = (xy_un[:, 0] - cx) / fx; y = (xy_un[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    cd = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * cd + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * cd + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return np.stack([fx * xd + cx, fy * yd + cy], 1)
+
+
+@pytest.mark.parametrize("dist", [TUM1_DIST, TUM1_DIST[:4], (-0.28, 0.07, 0.0002, 0.00002), (1e-3,)])
+def test_undistort_keypoints_matches_oracle(dist):
+    rng = np.random.default_rng(5)
+    k = np.stack([rng.uniform(0, 640, 1025), rng.uniform(0, 480, 1025)], 1).astype(np.float32)
+    got = frontend.host_undistort_keypoints(k, TUM1_K, dist)
+    ref = ho.undistort_keypoints(k, TUM1_K, dist)
+    assert got.dtype == np.float32 and got.shape == k.shape
+    assert np.array_equal(got, ref)                                   # same doubles, same order: bit-exact
+    if abs(dist[0]) > 0.05:
+        assert np.abs(got - k).max() > 0.5                            # it does move points
+
+
+def test_undistort_keypoints_inverts_the_distortion_model():
+    rng = np.random.default_rng(6)
+    un = np.stack([rng.uniform(60, 580, 500), rng.uniform(40, 440, 500)], 1)
+    dist = (-0.12, 0.03, 0.0004, -0.0003)
+    k = _distort(un, TUM1_K, dist).astype(np.float32)
+    got = frontend.host_undistort_keypoints(k, TUM1_K, dist)
+    assert np.abs(got - un).max() < 2e-2                              # five fixed-point iterations, mild distortion
+
+
+def test_undistort_keypoints_zero_k1_copies_and_bad_arguments():
+    k = np.array([[10.5, 20.25], [600.0, 470.0]], np.float32)
+    assert np.array_equal(frontend.host_undistort_keypoints(k, TUM1_K, (0.0, 0.3, 0.1, 0.1)), k)   # the reference's early return
+    assert np.array_equal(frontend.host_undistort_keypoints(k, TUM1_K, ()), k)
+    assert frontend.host_undistort_keypoints(np.zeros((0, 2), np.float32), TUM1_K, TUM1_DIST).shape == (0, 2)
+    with pytest.raises(frontend.DaniError):
+        frontend.host_undistort_keypoints(k, (0.0, 500.0, 320.0, 240.0), TUM1_DIST)
+    with pytest.raises(frontend.DaniError):
+        frontend.host_undistort_keypoints(k, TUM1_K, (0.1,) * 6)
