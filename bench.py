@@ -87,7 +87,7 @@ def main():
                          "steps are dealt round-robin to them.  2 gives ~+7 % frames/s by filling host-sync gaps, but the "
                          "per-kernel HIP-event durations behind `roofline` then include time shared with the other "
                          "sequence's kernels, so the default keeps one sequence for clean attribution")
-    ap.add_argument("--lg-gemm", choices=("f32", "bf16x3"), default="f32",
+    ap.add_argument("--lg-gemm", choices=("f32", "bf16x3", "bf16x3_all"), default="f32",
                     help="arithmetic of LightGlue's linear layers for the TIMED region (dani_lg_set_gemm): f32 = f32 MFMA in the "
                          "oracle's canonical order (default, the headline); bf16x3 = three-term bf16 operand split, f32-accurate. "
                          "A default run also reports the bf16x3 mode in `lg_gemm_bf16x3`, measured after the timed region")
@@ -127,8 +127,8 @@ def main():
     weights = dict(synth.superpoint_weights(0)); weights.update(synth.lightglue_weights(0)); weights.update(synth.yolo_weights(0))
     eng = frontend.Engine(device=local_rank, max_batch=B, max_width=W, max_height=H, weights=weights)
     eng.yolo_set_classes(synth.COCO_NAMES, synth.DYNAMIC_NAMES)   # coco.names is not shipped by the reference
-    if args.lg_gemm == "bf16x3":
-        eng.lg_set_gemm(eng.LG_GEMM_BF16X3)
+    if args.lg_gemm != "f32":
+        eng.lg_set_gemm(eng.LG_GEMM_BF16X3 if args.lg_gemm == "bf16x3" else eng.LG_GEMM_BF16X3_ALL)
 
     import threading
     NSEQ = max(1, args.sequences)
@@ -194,31 +194,34 @@ def main():
     eng.set_profiling(False)
     out = next(o for o in outs if o is not None)
 
-    # outside the timed region: the same workload with LightGlue's linear layers in the other arithmetic
-    x3 = None
+    # outside the timed region: the same workload with LightGlue's matrix products in the other arithmetics
+    side = {}
     if args.lg_gemm == "f32" and world == 1 and NSEQ == 1 and not args.no_side_modes:
-        ref = [(np.array(o["matches"]).copy(), np.array(o["scores"]).copy()) for o in step()]   # f32 mode, same pairing as below
-        eng.lg_set_gemm(eng.LG_GEMM_BF16X3)
-        run_steps(10, False)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        outs3, _, fe3, _, lin3 = run_steps(50, True)
-        torch.cuda.synchronize()
-        dt3 = time.perf_counter() - t1
-        eng.set_profiling(False)
+        ref = [(np.array(o["matches"]).copy(), np.array(o["scores"]).copy()) for o in step()]   # f32 mode
+        for key, mode, what in (("lg_gemm_bf16x3", eng.LG_GEMM_BF16X3, "linear layers"),
+                                ("lg_gemm_bf16x3_all", eng.LG_GEMM_BF16X3_ALL, "linear layers and attention contractions")):
+            eng.lg_set_gemm(mode)
+            run_steps(10, False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            outs3, _, fe3, attn3, lin3 = run_steps(50, True)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+            eng.set_profiling(False)
+            worst, flips = 0.0, 0
+            for (m_a, s_a), o in zip(ref, outs3[0]):
+                a = {tuple(x): float(v) for x, v in zip(m_a.tolist(), s_a)}
+                b = {tuple(x): float(v) for x, v in zip(np.array(o["matches"]).tolist(), np.array(o["scores"]))}
+                flips += len(set(a) ^ set(b))
+                worst = max([worst] + [abs(a[k] - b[k]) for k in set(a) & set(b)])
+            side[key] = {"value": round(B * 50 / dt3, 3), "unit": "frames/s", "steps": 50, "ms_per_step": round(dt3 / 50 * 1e3, 4),
+                         "lightglue_ms_per_step": round(float(fe3[2]), 3),
+                         "linear_avg_launch_ms": round(float(lin3[0]) / max(int(round(lin3[2])), 1), 4),
+                         "attention_avg_launch_ms": round(float(attn3[0]) / max(int(round(attn3[2])), 1), 4),
+                         "max_abs_score_diff_vs_f32_mode": worst, "matches_not_in_both": flips,
+                         "note": f"dani_lg_set_gemm({key[8:].upper()}): {what} as six bf16 MFMAs over three-term operand splits, "
+                                 "f32 accumulation; opt-in, not the headline"}
         eng.lg_set_gemm(eng.LG_GEMM_F32)
-        worst, flips = 0.0, 0
-        for (m_a, s_a), o in zip(ref, outs3[0]):
-            a = {tuple(x): float(v) for x, v in zip(m_a.tolist(), s_a)}
-            b = {tuple(x): float(v) for x, v in zip(np.array(o["matches"]).tolist(), np.array(o["scores"]))}
-            flips += len(set(a) ^ set(b))
-            worst = max([worst] + [abs(a[k] - b[k]) for k in set(a) & set(b)])
-        x3 = {"value": round(B * 50 / dt3, 3), "unit": "frames/s", "steps": 50, "ms_per_step": round(dt3 / 50 * 1e3, 4),
-              "lightglue_ms_per_step": round(float(fe3[2]), 3),
-              "linear_avg_launch_ms": round(float(lin3[0]) / max(int(round(lin3[2])), 1), 4),
-              "max_abs_score_diff_vs_f32_mode": worst, "matches_not_in_both": flips,
-              "note": "dani_lg_set_gemm(DANI_LG_GEMM_BF16X3): linear layers as six bf16 MFMAs over three-term operand splits, "
-                      "f32 accumulation; opt-in, not the headline"}
     gc.enable()
 
     dt_max = sharding.reduce_max_seconds(dt, reduce_dev)
@@ -250,7 +253,7 @@ def main():
             "metric": "frames/sec SuperPoint+LightGlue+YOLO front-end, 640x480, 1/2/4/8 MI355X",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.lg_gemm == "f32" else "f32 (LightGlue linear layers: bf16x3 operand split on the bf16 MFMA, f32 accumulate)", "data": "synthetic" + (" (frames handed over as HOST buffers: PCIe-inclusive)" if args.host_inputs else ""),
+            "vs_baseline": None, "dtype": "f32" if args.lg_gemm == "f32" else f"f32 (LightGlue matrix products: {args.lg_gemm} operand split on the bf16 MFMA, f32 accumulate)", "data": "synthetic" + (" (frames handed over as HOST buffers: PCIe-inclusive)" if args.host_inputs else ""),
             "config": {"workload": "full front-end (BASELINE config #4 sharded): YOLOv5s boxes -> SuperPoint extract -> "
                                    f"LightGlue vs previous frame, {B} synthetic 640x480 frames per GPU per step resident "
                                    "in HBM, nFeatures=1024, nLevels=1, iniTh=0.015, minTh=0.007, LightGlue 9 layers "
@@ -280,8 +283,7 @@ def main():
             "sp_conv_stack_tflops": round(SP_GFLOP_PER_FRAME * B / conv_ms, 2) if conv_ms > 0 else None,
             "layer_ms": [round(float(x), 4) for x in layer_ms],
         }
-        if x3 is not None:
-            res["lg_gemm_bf16x3"] = x3
+        res.update(side)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(frames[:4], frames_bgr[:4], weights)
         print(json.dumps(res), flush=True)

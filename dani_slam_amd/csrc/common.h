@@ -156,7 +156,7 @@ void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, i
 void launch_posenc(const LgSet* sets, int nsets, int max_span, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s);
 void launch_desc_to_fm(const LgSet* sets, int nsets, int max_span, float* x, int ld, hipStream_t s);
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
-                      int max_mp, int max_tail, int cross, float scale, hipStream_t s);
+                      int max_mp, int max_tail, int cross, float scale, hipStream_t s, int x3 = 0);   // x3: attn_x3_kernel (bf16x3 split contractions)
 void launch_lg_densify(const float* md, const float* logsig, const LgSet* sets, int nsets, int max_n, float* md_dense,
                        float* logsig_dense, int ld, hipStream_t s);
 void launch_matchability(const float* x, const float* w, float b, float* logsig, int T, int ld, hipStream_t s);

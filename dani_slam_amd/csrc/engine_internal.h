@@ -105,7 +105,7 @@ struct dani_engine {
   std::vector<dani::eng::Context*> ctxs;
   std::mutex mu;
   bool profiling = false;
-  int lg_gemm = 0;   // DANI_LG_GEMM_*: 0 = f32 MFMA in the canonical order, 1 = bf16x3 split (lg_x3.hip)
+  int lg_gemm = 0;   // DANI_LG_GEMM_*: 0 = f32 MFMA in the canonical order, 1 = bf16x3 split linears (lg_x3.hip), 2 = + attention
   dani::eng::LgWeights* lgw = nullptr;             // packed LightGlue / YOLO weights (owned; device buffers are in weight_allocs)
   dani::eng::YoloWeights* yw = nullptr;
   std::map<int, dani::eng::SeqState*> seqs;        // dani_frontend_batch sequences (own context + cached previous frame), under mu

@@ -258,14 +258,14 @@ void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
   int ai = 0, li = 0;
   auto attn = [&](const float* Q, const float* K, const float* V, int cross, float scale) {
     if (prof) (void)hipEventRecord(L->aev[ai++], s);
-    launch_attention(Q, K, V, L->ctx, ld, L->d_sets, nsets, sh.max_mp, sh.max_tail, cross, scale, s);
+    launch_attention(Q, K, V, L->ctx, ld, L->d_sets, nsets, sh.max_mp, sh.max_tail, cross, scale, s, gemm == DANI_LG_GEMM_BF16X3_ALL);
     if (prof) (void)hipEventRecord(L->aev[ai++], s);
   };
   launch_desc_to_fm(L->d_sets, nsets, sh.max_span, L->x, ld, s);
   launch_posenc(L->d_sets, nsets, sh.max_span, W->wr, L->cosb, L->sinb, ld, s);
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
-    if (gemm == DANI_LG_GEMM_BF16X3) launch_linear_x3(x0, K0, x1, K1, l.w3, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
+    if (gemm != DANI_LG_GEMM_F32) launch_linear_x3(x0, K0, x1, K1, l.w3, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
     else launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
   };
@@ -308,7 +308,7 @@ extern "C" {
 
 int dani_lg_set_gemm(dani_engine* e, int32_t mode) {
   if (!e) return DANI_ERR_INVALID;
-  if (mode != DANI_LG_GEMM_F32 && mode != DANI_LG_GEMM_BF16X3) return fail(e, DANI_ERR_INVALID, "unknown LightGlue GEMM mode %d", mode);
+  if (mode != DANI_LG_GEMM_F32 && mode != DANI_LG_GEMM_BF16X3 && mode != DANI_LG_GEMM_BF16X3_ALL) return fail(e, DANI_ERR_INVALID, "unknown LightGlue GEMM mode %d", mode);
   e->lg_gemm = mode;
   return DANI_OK;
 }

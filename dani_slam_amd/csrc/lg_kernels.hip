@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "lin_epilogue.h"
+#include "x3_common.h"
 
 namespace dani {
 
@@ -708,10 +709,221 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// attn_x3_kernel: attn_ks_kernel with both contractions on the bf16 matrix cores at f32 accuracy (x3_common.h; the
+// DANI_LG_GEMM_BF16X3_ALL option).  Same workgroup shape (64 queries = 2 query blocks x 2 key halves), same online
+// softmax in f32, same tail-key / tail-query / merge code.  What changes:
+//   * Q is split once into B fragments in registers (lane = query, 8 consecutive d per k-step and lane half);
+//   * a K tile is split while staging into three [key][d] bf16 planes (128-B rows, 16-B slots XOR-swizzled by key
+//     pair) -- the A operand of S^T = K Q^T;
+//   * a V tile is split into three [d][key] bf16 planes whose 32 keys are stored in the order the S^T accumulator
+//     holds them: register r = 8t + e of lane half h is key 16t + 4h + e (e < 4) or 16t + 8 + 4h + (e - 4), so fragment
+//     (t, h) of a V row is [keys 16t+4h..+3 | keys 16t+8+4h..+3] = two of the staging thread's float4 -- and the
+//     probabilities, split in place, ARE the B operand of O^T = V^T P^T, register for register (no shuffle, no LDS);
+//   * per key tile and wave 24 + 24 bf16 MFMAs (32 cycles each) replace 32 + 32 f32 MFMAs (64 cycles each).
+// ---------------------------------------------------------------------------------------------
+constexpr int AX_KPLANE = 32 * 128, AX_VPLANE = 64 * 64, AX_HALF = 3 * AX_KPLANE + 3 * AX_VPLANE;   // bytes
+
+__global__ __launch_bounds__(256, 2) void attn_x3_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
+                                                         const LgSet* sets, int tail_slots, int cross, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char sKV[2 * AX_HALF];   // [key half][K hi|mid|lo][V hi|mid|lo]
+  __shared__ float sTK[LG_TAIL_MAX * 128];
+  int bx, head, bz;
+  const int tail_q = attn_role(tail_slots, bx, head, bz);
+  const LgSet st = sets[bz];
+  if (tail_q >= 0) { attn_tail_query(Q, K, V, O, ld, st, tail_q, head, cross, scale, reinterpret_cast<float*>(sKV)); return; }
+  const int np = (st.nmain + 31) & ~31;
+  const int q0 = bx * 64;
+  if (q0 >= np) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const int qb = wave & 1, kh = wave >> 1;
+  const AttnKeys ks = attn_keys(st, cross);
+  const int k_off = ks.off, k_n = ks.nmain;
+  const int qi = q0 + qb * 32 + j;
+  const bool wave_active = (q0 + qb * 32) < np;
+  const int qtok = st.tok_off + min(qi, np - 1);
+  const float* Qh = Q + (size_t)head * 64 * ld;
+  const float* Kh = K + (size_t)head * 64 * ld + k_off;
+  const float* Vh = V + (size_t)head * 64 * ld + k_off;
+  const unsigned char* sK = sKV + kh * AX_HALF;
+  const unsigned char* sV = sK + 3 * AX_KPLANE;
+  if (ks.n > ks.nmain)
+    attn_stage_tail_keys(K + (size_t)head * 64 * ld, V + (size_t)head * 64 * ld, ld, ks.tail_off, ks.n - ks.nmain, sTK);
+
+  // Q fragments: k-step s (16 d), plane p; lane (query j, half h) holds d = 16 s + 8 h + 0..7
+  const float qscale = scale * 1.44269504088896341f;   // base-2 softmax
+  u32x4 qf[4][3];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const float a0 = Qh[(size_t)(16 * s4 + 8 * h + e) * ld + qtok] * qscale;
+      const float a1 = Qh[(size_t)(16 * s4 + 8 * h + e + 1) * ld + qtok] * qscale;
+      unsigned hi, mid, lo;
+      x3_split2(a0, a1, hi, mid, lo);
+      qf[s4][0][e >> 1] = hi; qf[s4][1][e >> 1] = mid; qf[s4][2][e >> 1] = lo;
+    }
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
+  float m = -1e30f, l = 0.0f;
+
+  const int ntiles = (k_n + 31) / 32, half = (ntiles + 1) / 2;
+  // staging roles (per iteration: one key tile per key half).  Threads 0..127 serve key half 0, 128..255 half 1.
+  //   K: 4 consecutive d rows x 4 consecutive keys per thread (transposed into [key][d]: one 8-B store per key and plane);
+  //      a 16-lane store group = 4 key groups x 4 d groups -> 16 different 8-B columns of the 128-B bank row
+  //   V: 4 float4 (one d row, 4 consecutive keys each) per thread, stored as they are (one 8-B store per plane)
+  const int hh = tid >> 7, idx = tid & 127;
+  const int kq4 = ((idx >> 4) & 1) * 4 + (idx & 3), kdg = (idx >> 5) * 4 + ((idx >> 2) & 3);
+  f32x4 pk[4], pv[4];
+  const float* ksrc = Kh + (size_t)(4 * kdg) * ld + 4 * kq4;
+  const float* vsrc[4];
+  unsigned voff[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int e2 = idx + 128 * u, q4 = e2 & 7, d = e2 >> 3;
+    vsrc[u] = Vh + (size_t)d * ld + 4 * q4;
+    const int slot = (q4 >> 2) * 2 + (q4 & 1), part = (q4 >> 1) & 1;
+    voff[u] = (unsigned)(hh * AX_HALF + 3 * AX_KPLANE + d * 64 + (((slot ^ ((d >> 2) & 3)) << 4) | (part << 3)));
+  }
+  unsigned char* kdst = sKV + hh * AX_HALF;
+#define AX_PREFETCH(it_)                                                                       \
+  {                                                                                            \
+    const int tl_ = max(min(hh * half + (it_), ntiles - 1), 0) * 32;                           \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                            \
+      pk[u] = *reinterpret_cast<const f32x4*>(ksrc + (size_t)u * ld + tl_);                    \
+      pv[u] = *reinterpret_cast<const f32x4*>(vsrc[u] + tl_);                                  \
+    }                                                                                          \
+  }
+  AX_PREFETCH(0);
+  for (int it = 0; it < half; it++) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {          // K: key 4 kq4 + c, d = 4 kdg .. +3
+      unsigned h0, m0, l0, h1, m1, l1;
+      x3_split2(pk[0][c], pk[1][c], h0, m0, l0);
+      x3_split2(pk[2][c], pk[3][c], h1, m1, l1);
+      const int key = 4 * kq4 + c;
+      unsigned char* dst = kdst + key * 128 + ((((kdg >> 1) ^ ((key >> 1) & 7)) << 4) | ((kdg & 1) << 3));
+      *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(dst + AX_KPLANE) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(dst + 2 * AX_KPLANE) = u32x2{l0, l1};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {          // V: one d row, 4 consecutive keys
+      unsigned h0, m0, l0, h1, m1, l1;
+      x3_split2(pv[u][0], pv[u][1], h0, m0, l0);
+      x3_split2(pv[u][2], pv[u][3], h1, m1, l1);
+      unsigned char* dst = sKV + voff[u];
+      *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(dst + AX_VPLANE) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(dst + 2 * AX_VPLANE) = u32x2{l0, l1};
+    }
+    __syncthreads();
+    AX_PREFETCH(min(it + 1, max(half - 1, 0)));
+    __builtin_amdgcn_sched_barrier(0);
+    const int kt = kh * half + it;
+    if (wave_active && kt < ntiles) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = 0.0f;
+      // S^T[key][query] = K[key][:] . Q[query][:]
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        const unsigned char* ap = sK + j * 128 + (((2 * s4 + h) ^ ((j >> 1) & 7)) << 4);
+        const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ap);
+        const bf16x8 a_m = *reinterpret_cast<const bf16x8*>(ap + AX_KPLANE);
+        const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(ap + 2 * AX_KPLANE);
+        x3_mfma6(s, a_h, a_m, a_l, __builtin_bit_cast(bf16x8, qf[s4][0]), __builtin_bit_cast(bf16x8, qf[s4][1]),
+                 __builtin_bit_cast(bf16x8, qf[s4][2]));
+      }
+      const int kbase = kt * 32;
+      if (kbase + 32 > k_n) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (kbase + acc_row(r, h) >= k_n) s[r] = -1e30f;
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m, mx);
+      float ls = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ls += s[r]; }
+      if (__ballot(m_new > m)) {
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      }
+      l += ls;
+      m = m_new;
+      // O^T[d][query] += V[key][d] P[query][key]: registers 8t .. 8t+7 of the S^T accumulator are k-step t of the B operand
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          unsigned hi, mid, lo;
+          x3_split2(s[8 * t + e], s[8 * t + e + 1], hi, mid, lo);
+          ph[e >> 1] = hi; pm[e >> 1] = mid; pl[e >> 1] = lo;
+        }
+#pragma unroll
+        for (int db = 0; db < 2; db++) {
+          const int d = db * 32 + j;
+          const unsigned char* vp = sV + d * 64 + (((2 * t + h) ^ ((d >> 2) & 3)) << 4);
+          const bf16x8 v_h = *reinterpret_cast<const bf16x8*>(vp);
+          const bf16x8 v_m = *reinterpret_cast<const bf16x8*>(vp + AX_VPLANE);
+          const bf16x8 v_l = *reinterpret_cast<const bf16x8*>(vp + 2 * AX_VPLANE);
+          x3_mfma6(o[db], v_h, v_m, v_l, __builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl));
+        }
+      }
+    }
+  }
+#undef AX_PREFETCH
+  if (ks.n > ks.nmain) {                                  // tail keys on the VALU, with the f32 query in attn_ks_kernel's layout
+    if (half == 0) __syncthreads();
+    if (kh == 1 && wave_active) {
+      float qreg[32];
+#pragma unroll
+      for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * qscale;
+      attn_tail_keys(sTK, ks.n - ks.nmain, qreg, o, m, l, h);
+    }
+  }
+  // ---- merge the two key halves of each query block through LDS (reusing the tile buffers)
+  __syncthreads();
+  float* xch = reinterpret_cast<float*>(sKV) + (size_t)qb * (64 * 34);
+  if (kh == 1) {
+    float* p = xch + lane * 34;
+    p[0] = m; p[1] = l;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { p[2 + r] = o[0][r]; p[18 + r] = o[1][r]; }
+  }
+  __syncthreads();
+  if (kh == 0 && qi < np) {
+    const float* p = xch + lane * 34;
+    const float m1 = p[0], l1 = p[1];
+    const float mm = fmaxf(m, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+    const float lt0 = l * a0 + l1 * a1;
+    const float lt = lt0 + __shfl_xor(lt0, 32);
+    const float inv = (lt > 0.0f && qi < st.nmain) ? 1.0f / lt : 0.0f;
+    float* Oh = O + (size_t)head * 64 * ld + st.tok_off + qi;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      Oh[(size_t)acc_row(r, h) * ld] = (o[0][r] * a0 + p[2 + r] * a1) * inv;
+      Oh[(size_t)(32 + acc_row(r, h)) * ld] = (o[1][r] * a0 + p[18 + r] * a1) * inv;
+    }
+  }
+}
+
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
-                      int max_mp, int max_tail, int cross, float scale, hipStream_t s) {
+                      int max_mp, int max_tail, int cross, float scale, hipStream_t s, int x3) {
   // grid.x: query tiles of the main regions + max_tail slots per (head, set) for the tail-query workgroups (attn_role)
-  if (((max_mp + 127) / 128) * 4 * nsets >= 1024)
+  if (x3)
+    hipLaunchKernelGGL(attn_x3_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+  else if (((max_mp + 127) / 128) * 4 * nsets >= 1024)
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   else
     hipLaunchKernelGGL(attn_ks_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);

@@ -18,6 +18,7 @@
 // with one 16-B load per lane straight from L2 (393 KB per 256x256 layer), two k-steps ahead of their use.
 #include "common.h"
 #include "lin_epilogue.h"
+#include "x3_common.h"
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -27,11 +28,6 @@ namespace dani {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct LinX3Args {
   const float* x0; const float* x1; int K0, K1;
@@ -45,16 +41,6 @@ struct LinX3Args {
 namespace {
 constexpr int X3_TT = 64, X3_KC = 64, X3_PLANE = X3_TT * X3_KC * 2;   // bytes per LDS plane
 
-// two f32 -> packed (hi | mid | lo) bf16 pairs
-__device__ __forceinline__ void x3_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  f32x2 v = {a, b};
-  bf16x2 h = __builtin_convertvector(v, bf16x2);
-  f32x2 r1 = v - __builtin_convertvector(h, f32x2);      // exact
-  bf16x2 m = __builtin_convertvector(r1, bf16x2);
-  f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);     // exact
-  bf16x2 l = __builtin_convertvector(r2, bf16x2);
-  hi = __builtin_bit_cast(unsigned, h); mid = __builtin_bit_cast(unsigned, m); lo = __builtin_bit_cast(unsigned, l);
-}
 }  // namespace
 
 // NCB = 32-row output blocks per wave: 1 -> workgroup = 64 outputs x 64 tokens (shipped), 2 -> 128 outputs x 64 tokens
@@ -145,13 +131,7 @@ __global__ __launch_bounds__(256, NCB == 1 ? 4 : 3) void linear_x3_kernel(LinX3A
         const bf16x8 ah = __builtin_bit_cast(bf16x8, pa[s & 1][cb][0]);
         const bf16x8 am = __builtin_bit_cast(bf16x8, pa[s & 1][cb][1]);
         const bf16x8 al = __builtin_bit_cast(bf16x8, pa[s & 1][cb][2]);
-        // smallest terms first
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[cb], 0, 0, 0);
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[cb], 0, 0, 0);
+        x3_mfma6(acc[cb], ah, am, al, bh, bm, bl);
       }
       prefetch_a(min(ch * 4 + s + 2, nsteps - 1), s & 1);
       __builtin_amdgcn_sched_barrier(0);

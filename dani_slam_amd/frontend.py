@@ -538,10 +538,10 @@ class Engine:
         fv = {int(fn[i]): ff[fo[i]:fo[i + 1]].tolist() for i in range(nf.value)}
         return bow, fv
 
-    LG_GEMM_F32, LG_GEMM_BF16X3 = 0, 1
+    LG_GEMM_F32, LG_GEMM_BF16X3, LG_GEMM_BF16X3_ALL = 0, 1, 2
 
     def lg_set_gemm(self, mode):
-        """Arithmetic of LightGlue's linear layers: LG_GEMM_F32 (default, canonical order) or LG_GEMM_BF16X3."""
+        """Arithmetic of LightGlue's linear layers: LG_GEMM_F32 (default, canonical order), LG_GEMM_BF16X3 (linear layers) or LG_GEMM_BF16X3_ALL (+ attention)."""
         self._check(self.lib.dani_lg_set_gemm(self.h, int(mode)))
 
     def set_profiling(self, on=True):

@@ -133,16 +133,19 @@ DANI_API int dani_last_timings(dani_engine* e, float* ms, int32_t n);
 
 /* ---- LightGlue matching -------------------------------------------------------------------- */
 
-/* Arithmetic of LightGlue's linear layers (the dominant kernel of the front-end).  Both modes compute the same
- * function to f32 accuracy and meet the 1e-3 score tolerance with the same margin (tests/test_lg_gpu.py):
- *   DANI_LG_GEMM_F32     (default) f32 MFMA, accumulation in the canonical order of the oracle.
- *   DANI_LG_GEMM_BF16X3  every f32 operand split into three bf16 terms, six bf16 MFMAs per product block, f32
- *                        accumulation: error against an f64 contraction within 2x of the f32 mode's, ~1.35x faster
- *                        per layer on MI355X; the additions are NOT in the canonical order.
+/* Arithmetic of LightGlue's matrix products (linear layers: the dominant kernel of the front-end; attention: the
+ * second).  All modes compute the same function to f32 accuracy and meet the 1e-3 score tolerance with the same margin
+ * (tests/test_lg_gpu.py):
+ *   DANI_LG_GEMM_F32         (default) f32 MFMA, accumulation in the canonical order of the oracle.
+ *   DANI_LG_GEMM_BF16X3      linear layers: every f32 operand split into three bf16 terms, six bf16 MFMAs per product
+ *                            block, f32 accumulation (error against an f64 contraction within 2x of the f32 mode's);
+ *                            the additions are NOT in the canonical order.
+ *   DANI_LG_GEMM_BF16X3_ALL  the same for the attention contractions (K Q^T and V^T P^T) as well; softmax stays f32.
  * Applies to the next dani_lg_match* / dani_frontend_batch calls of this engine.  SuperPoint and YOLO are not
  * affected (they are bit-exact against the oracle and stay on the f32 path). */
 #define DANI_LG_GEMM_F32 0
 #define DANI_LG_GEMM_BF16X3 1
+#define DANI_LG_GEMM_BF16X3_ALL 2
 DANI_API int dani_lg_set_gemm(dani_engine* e, int32_t mode);
 
 /* Replaces LightGlue::matchDescriptors + normalizeKeypoints + filterMatches (src/LightGlue.cpp:18-122), as

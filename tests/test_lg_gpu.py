@@ -69,16 +69,17 @@ def test_pair_matches_oracle(engine, lg_weights, n0, n1):
     assert np.all(np.diff(m[:, 0]) > 0) if len(m) > 1 else True   # increasing queryIdx order
 
 
-@pytest.mark.parametrize("n0,n1", [(1024, 1024), (1025, 1025), (7, 7), (40, 1030), (2049, 1999)])
-def test_bf16x3_linears_match_oracle_and_f32_mode(engine, lg_weights, n0, n1):
-    """dani_lg_set_gemm(DANI_LG_GEMM_BF16X3): the linear layers on the bf16 matrix cores with three-term operand splits
-    (csrc/lg_x3.hip).  Same bar against the oracle as the default mode (_check_pair: final descriptors 2e-4, scores
+@pytest.mark.parametrize("mode", ["LG_GEMM_BF16X3", "LG_GEMM_BF16X3_ALL"])
+@pytest.mark.parametrize("n0,n1", [(1024, 1024), (1025, 1025), (7, 7), (40, 1030), (2049, 1999), (35, 36), (64, 70)])
+def test_bf16x3_modes_match_oracle_and_f32_mode(engine, lg_weights, n0, n1, mode):
+    """dani_lg_set_gemm(DANI_LG_GEMM_BF16X3 / _ALL): the linear layers (and the attention contractions) on the bf16 matrix
+    cores with three-term operand splits (csrc/lg_x3.hip, attn_x3_kernel).  Same bar against the oracle as the default mode (_check_pair: final descriptors 2e-4, scores
     1e-3), and within 1e-4 of the f32-MFMA mode on every score -- both are f32-accurate, only the order of the
     additions differs."""
     k0, d0, k1, d1, _ = synth.matching_pair(n0 + n1, n0=n0, n1=n1)
     m32, s32 = engine.lg_match(k0, d0, k1, d1, SIZE, SIZE, 0.05)
     g32, _, mx32 = engine.lg_debug_fetch(0, n0)
-    engine.lg_set_gemm(engine.LG_GEMM_BF16X3)
+    engine.lg_set_gemm(getattr(engine, mode))
     try:
         m3, s3, _, _ = _check_pair(engine, lg_weights, k0, d0, k1, d1)
         g3, _, mx3 = engine.lg_debug_fetch(0, n0)
