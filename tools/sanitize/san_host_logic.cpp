@@ -25,6 +25,15 @@ int main() {
   for (auto& v : ul) v = ux(rng); for (auto& v : ur) v = ux(rng);
   for (int i = 0; i < 300; i++) { m[2*i] = rng() % 500; m[2*i+1] = rng() % 480; s[i] = (rng() % 1000) / 1000.0f; }
   stereo_from_matches(ul.data(), 500, ur.data(), 480, m.data(), s.data(), 300, 0.1f, 40.0f, u.data(), d.data());
+  {   // UndistortKeyPoints: TUM1-like coefficients, in place, and the degenerate inputs
+    const float K4[4] = {517.3f, 516.5f, 318.6f, 255.3f}, dist[5] = {0.2624f, -0.9531f, -0.0054f, 0.0026f, 1.1633f}, zero[4] = {0, 0.3f, 0, 0};
+    std::vector<float> kk(k.begin(), k.begin() + 2 * 1025), un(2 * 1025);
+    undistort_keypoints(kk.data(), 1025, K4, dist, 5, un.data());
+    undistort_keypoints(kk.data(), 1025, K4, dist, 4, kk.data());
+    undistort_keypoints(kk.data(), 1025, K4, zero, 4, un.data());
+    undistort_keypoints(nullptr, 0, K4, dist, 5, nullptr);
+    printf("undistort ok %f\n", un[0]);
+  }
   // YOLO host
   std::vector<float> c8(8 * 400), dets(6 * 400);
   for (int i = 0; i < 400; i++) { int id = i; memcpy(&c8[8*i], &id, 4); c8[8*i+1] = ux(rng); c8[8*i+2] = uy(rng); c8[8*i+3] = 50; c8[8*i+4] = 60; c8[8*i+5] = 0.9f; c8[8*i+6] = 0.8f; int cl = i % 80; memcpy(&c8[8*i+7], &cl, 4); }
