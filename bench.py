@@ -196,15 +196,16 @@ def main():
 
     # outside the timed region: the same workload with LightGlue's matrix products in the other arithmetics
     side = {}
+    SIDE_STEPS = 100
     if args.lg_gemm == "f32" and world == 1 and NSEQ == 1 and not args.no_side_modes:
         ref = [(np.array(o["matches"]).copy(), np.array(o["scores"]).copy()) for o in step()]   # f32 mode
         for key, mode, what in (("lg_gemm_bf16x3", eng.LG_GEMM_BF16X3, "linear layers"),
                                 ("lg_gemm_bf16x3_all", eng.LG_GEMM_BF16X3_ALL, "linear layers and attention contractions")):
             eng.lg_set_gemm(mode)
-            run_steps(10, False)
+            run_steps(20, False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            outs3, _, fe3, attn3, lin3 = run_steps(50, True)
+            outs3, _, fe3, attn3, lin3 = run_steps(SIDE_STEPS, True)
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t1
             eng.set_profiling(False)
@@ -214,7 +215,7 @@ def main():
                 b = {tuple(x): float(v) for x, v in zip(np.array(o["matches"]).tolist(), np.array(o["scores"]))}
                 flips += len(set(a) ^ set(b))
                 worst = max([worst] + [abs(a[k] - b[k]) for k in set(a) & set(b)])
-            side[key] = {"value": round(B * 50 / dt3, 3), "unit": "frames/s", "steps": 50, "ms_per_step": round(dt3 / 50 * 1e3, 4),
+            side[key] = {"value": round(B * SIDE_STEPS / dt3, 3), "unit": "frames/s", "steps": SIDE_STEPS, "ms_per_step": round(dt3 / SIDE_STEPS * 1e3, 4),
                          "lightglue_ms_per_step": round(float(fe3[2]), 3),
                          "linear_avg_launch_ms": round(float(lin3[0]) / max(int(round(lin3[2])), 1), 4),
                          "attention_avg_launch_ms": round(float(attn3[0]) / max(int(round(attn3[2])), 1), 4),
@@ -284,6 +285,14 @@ def main():
             "layer_ms": [round(float(x), 4) for x in layer_ms],
         }
         res.update(side)
+        try:   # the facts the peaks in `roofline` are priced against (print them next to every roofline number)
+            pr = torch.cuda.get_device_properties(dev)
+            res["device"] = {"name": pr.name, "arch": getattr(pr, "gcnArchName", None), "compute_units": pr.multi_processor_count,
+                             "hbm_gib": round(pr.total_memory / 2**30, 1),
+                             "max_engine_clock_mhz": round(getattr(pr, "clock_rate", 0) / 1000) or None,
+                             "fp32_matrix_peak_tflops_used": FP32_MATRIX_PEAK_TFLOPS}
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(frames[:4], frames_bgr[:4], weights)
         print(json.dumps(res), flush=True)
