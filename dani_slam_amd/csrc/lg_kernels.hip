@@ -942,12 +942,17 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const float* Q, const f
   }
 }
 
+int g_attn_force = 0;   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel
+
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_mp, int max_tail, int cross, float scale, hipStream_t s, int x3) {
   // grid.x: query tiles of the main regions + max_tail slots per (head, set) for the tail-query workgroups (attn_role)
-  if (x3)
+  if (x3 || g_attn_force == 3)
     hipLaunchKernelGGL(attn_x3_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
-  else if (((max_mp + 127) / 128) * 4 * nsets >= 1024)
+  // 128-query workgroups (no key split, half the tile staging per MFMA, no merge) once they fill the chip's 512 resident
+  // slots in whole rounds; below that the key-split kernel's twice as many, half as long workgroups balance better.
+  // At 16 x 1025 keypoints (512 workgroups = one round): 150.1 vs 156.0 us (tools/probes/attn_bench.hip).
+  else if (g_attn_force != 1 && (g_attn_force == 2 || ((max_mp + 127) / 128) * 4 * nsets >= 512))
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   else
     hipLaunchKernelGGL(attn_ks_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
