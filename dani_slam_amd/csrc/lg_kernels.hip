@@ -942,12 +942,184 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(const float* Q, const f
   }
 }
 
-int g_attn_force = 0;   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel
+// ---------------------------------------------------------------------------------------------
+// attn_x3w_kernel: the 128-query form of attn_x3_kernel (attn_kernel<4>'s structure: 4 waves = 4 query blocks, every
+// wave consumes every staged key tile, no key split and no merge).  One K/V tile is split per iteration by all 256
+// threads -- half the split work per MFMA of the key-split form -- and used by 4 waves.  Same fragments and LDS layouts.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_x3w_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
+                                                          const LgSet* sets, int tail_slots, int cross, float scale) {
+  __shared__ __attribute__((aligned(16))) unsigned char sKV[AX_HALF];   // [K hi|mid|lo][V hi|mid|lo]
+  __shared__ float sTK[LG_TAIL_MAX * 128];
+  int bx, head, bz;
+  const int tail_q = attn_role(tail_slots, bx, head, bz);
+  const LgSet st = sets[bz];
+  if (tail_q >= 0) { attn_tail_query(Q, K, V, O, ld, st, tail_q, head, cross, scale, reinterpret_cast<float*>(sKV)); return; }
+  const int mp = (st.nmain + 31) & ~31;
+  const int q0 = bx * 128;
+  if (q0 >= mp) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  const AttnKeys ks = attn_keys(st, cross);
+  const int k_off = ks.off, k_n = ks.nmain;
+  const int qi = q0 + wave * 32 + j;
+  const int qtok = st.tok_off + min(qi, mp - 1);
+  const float* Qh = Q + (size_t)head * 64 * ld;
+  const float* Kh = K + (size_t)head * 64 * ld + k_off;
+  const float* Vh = V + (size_t)head * 64 * ld + k_off;
+  const unsigned char* sK = sKV;
+  const unsigned char* sV = sKV + 3 * AX_KPLANE;
+  if (ks.n > ks.nmain)
+    attn_stage_tail_keys(K + (size_t)head * 64 * ld, V + (size_t)head * 64 * ld, ld, ks.tail_off, ks.n - ks.nmain, sTK);
+
+  const float qscale = scale * 1.44269504088896341f;
+  u32x4 qf[4][3];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const float a0 = Qh[(size_t)(16 * s4 + 8 * h + e) * ld + qtok] * qscale;
+      const float a1 = Qh[(size_t)(16 * s4 + 8 * h + e + 1) * ld + qtok] * qscale;
+      unsigned hi, mid, lo;
+      x3_split2(a0, a1, hi, mid, lo);
+      qf[s4][0][e >> 1] = hi; qf[s4][1][e >> 1] = mid; qf[s4][2][e >> 1] = lo;
+    }
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
+  float m = -1e30f, l = 0.0f;
+
+  const int ntiles = (k_n + 31) / 32;
+  // staging roles, 256 threads for one tile.  K: 2 consecutive d rows x 4 consecutive keys per thread -> one 4-B store
+  // per key and plane; a 32-lane store group = 4 key groups x 8 d pairs -> 32 different dwords of the 128-B bank row.
+  // V: 2 float4 (one d row, 4 consecutive keys each) per thread, one 8-B store per plane.
+  const int kq4 = ((tid >> 5) & 1) * 4 + (tid & 3), kdg = (tid >> 6) * 8 + ((tid >> 2) & 7);   // d = 2 kdg, 2 kdg + 1
+  f32x4 pk[2], pv[2];
+  const float* ksrc = Kh + (size_t)(2 * kdg) * ld + 4 * kq4;
+  const float* vsrc[2];
+  unsigned voff[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int e2 = tid + 256 * u, q4 = e2 & 7, d = e2 >> 3;
+    vsrc[u] = Vh + (size_t)d * ld + 4 * q4;
+    const int slot = (q4 >> 2) * 2 + (q4 & 1), part = (q4 >> 1) & 1;
+    voff[u] = (unsigned)(3 * AX_KPLANE + d * 64 + (((slot ^ ((d >> 2) & 3)) << 4) | (part << 3)));
+  }
+#define AXW_PREFETCH(kt_)                                                                      \
+  {                                                                                            \
+    const int tl_ = max(min((kt_), ntiles - 1), 0) * 32;                                       \
+    _Pragma("unroll") for (int u = 0; u < 2; u++) {                                            \
+      pk[u] = *reinterpret_cast<const f32x4*>(ksrc + (size_t)u * ld + tl_);                    \
+      pv[u] = *reinterpret_cast<const f32x4*>(vsrc[u] + tl_);                                  \
+    }                                                                                          \
+  }
+  AXW_PREFETCH(0);
+  for (int kt = 0; kt < ntiles; kt++) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; c++) {          // K: key 4 kq4 + c, d = 2 kdg, 2 kdg + 1
+      unsigned h0, m0, l0;
+      x3_split2(pk[0][c], pk[1][c], h0, m0, l0);
+      const int key = 4 * kq4 + c;
+      unsigned char* dst = sKV + key * 128 + ((((kdg >> 2) ^ ((key >> 1) & 7)) << 4) | ((kdg & 3) << 2));
+      *reinterpret_cast<unsigned*>(dst) = h0;
+      *reinterpret_cast<unsigned*>(dst + AX_KPLANE) = m0;
+      *reinterpret_cast<unsigned*>(dst + 2 * AX_KPLANE) = l0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      unsigned h0, m0, l0, h1, m1, l1;
+      x3_split2(pv[u][0], pv[u][1], h0, m0, l0);
+      x3_split2(pv[u][2], pv[u][3], h1, m1, l1);
+      unsigned char* dst = sKV + voff[u];
+      *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+      *reinterpret_cast<u32x2*>(dst + AX_VPLANE) = u32x2{m0, m1};
+      *reinterpret_cast<u32x2*>(dst + 2 * AX_VPLANE) = u32x2{l0, l1};
+    }
+    __syncthreads();
+    AXW_PREFETCH(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = 0.0f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {
+      const unsigned char* ap = sK + j * 128 + (((2 * s4 + h) ^ ((j >> 1) & 7)) << 4);
+      const bf16x8 a_h = *reinterpret_cast<const bf16x8*>(ap);
+      const bf16x8 a_m = *reinterpret_cast<const bf16x8*>(ap + AX_KPLANE);
+      const bf16x8 a_l = *reinterpret_cast<const bf16x8*>(ap + 2 * AX_KPLANE);
+      x3_mfma6(s, a_h, a_m, a_l, __builtin_bit_cast(bf16x8, qf[s4][0]), __builtin_bit_cast(bf16x8, qf[s4][1]),
+               __builtin_bit_cast(bf16x8, qf[s4][2]));
+    }
+    const int kbase = kt * 32;
+    if (kbase + 32 > k_n) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (kbase + acc_row(r, h) >= k_n) s[r] = -1e30f;
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    float ls = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ls += s[r]; }
+    if (__ballot(m_new > m)) {
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    }
+    l += ls;
+    m = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      u32x4 ph, pm, pl;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        unsigned hi, mid, lo;
+        x3_split2(s[8 * t + e], s[8 * t + e + 1], hi, mid, lo);
+        ph[e >> 1] = hi; pm[e >> 1] = mid; pl[e >> 1] = lo;
+      }
+#pragma unroll
+      for (int db = 0; db < 2; db++) {
+        const int d = db * 32 + j;
+        const unsigned char* vp = sV + d * 64 + (((2 * t + h) ^ ((d >> 2) & 3)) << 4);
+        const bf16x8 v_h = *reinterpret_cast<const bf16x8*>(vp);
+        const bf16x8 v_m = *reinterpret_cast<const bf16x8*>(vp + AX_VPLANE);
+        const bf16x8 v_l = *reinterpret_cast<const bf16x8*>(vp + 2 * AX_VPLANE);
+        x3_mfma6(o[db], v_h, v_m, v_l, __builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl));
+      }
+    }
+  }
+#undef AXW_PREFETCH
+  if (ks.n > ks.nmain) {
+    if (ntiles == 0) __syncthreads();
+    float qreg[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * qscale;
+    attn_tail_keys(sTK, ks.n - ks.nmain, qreg, o, m, l, h);
+  }
+  const float lt = l + __shfl_xor(l, 32);
+  const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+  if (qi < mp) {
+    const float keep = qi < st.nmain ? inv : 0.0f;
+    float* Oh = O + (size_t)head * 64 * ld + st.tok_off + qi;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) Oh[(size_t)(db * 32 + acc_row(r, h)) * ld] = qi < st.nmain ? o[db][r] * keep : 0.0f;
+  }
+}
+
+int g_attn_force = 0;   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel, 4 = attn_x3w_kernel
 
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_mp, int max_tail, int cross, float scale, hipStream_t s, int x3) {
   // grid.x: query tiles of the main regions + max_tail slots per (head, set) for the tail-query workgroups (attn_role)
-  if (x3 || g_attn_force == 3)
+  if ((x3 && g_attn_force == 0 && ((max_mp + 127) / 128) * 4 * nsets >= 512) || g_attn_force == 4)   // as for the f32 pair below
+    hipLaunchKernelGGL(attn_x3w_kernel, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+  else if (x3 || g_attn_force == 3)
     hipLaunchKernelGGL(attn_x3_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   // 128-query workgroups (no key split, half the tile staging per MFMA, no merge) once they fill the chip's 512 resident
   // slots in whole rounds; below that the key-split kernel's twice as many, half as long workgroups balance better.

@@ -146,6 +146,19 @@ def test_large_batch_kernel_with_ragged_sets(lg_weights, sp_weights):
         m, s = e.lg_match(k0, d0, k1, d1, SIZE, SIZE, 0.05)
         assert np.array_equal(res[p][0], m), p
         np.testing.assert_allclose(res[p][1], s, rtol=0, atol=1e-4)      # two kernels, two summation orders
+    # the bf16x3 mode takes the 128-query kernel of ITS pair here (attn_x3w_kernel) and the key-split one for single pairs
+    e.lg_set_gemm(e.LG_GEMM_BF16X3_ALL)
+    res3 = e.lg_match_batch(K0, D0, [a for a, _ in sizes], K1, D1, [b for _, b in sizes], SIZE, SIZE, 0.05)
+    for p in range(16):
+        a = {tuple(x): v for x, v in zip(res[p][0].tolist(), res[p][1])}; b = {tuple(x): v for x, v in zip(res3[p][0].tolist(), res3[p][1])}
+        common = set(a) & set(b)
+        assert len(common) >= max(len(a), len(b)) - 2, p               # a near-tie may flip, nothing more
+        assert all(abs(a[c] - b[c]) < 1e-4 for c in common), p
+    for p in (0, 3, 15):
+        k0, d0, k1, d1, _ = pairs[p]
+        m, s = e.lg_match(k0, d0, k1, d1, SIZE, SIZE, 0.05)
+        assert np.array_equal(res3[p][0], m), p
+        np.testing.assert_allclose(res3[p][1], s, rtol=0, atol=1e-4)
     e.close()
 
 
