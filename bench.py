@@ -12,11 +12,15 @@ ranks with no data-path collective (weak scaling).
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel by total time (the f32 flash-attention kernel of LightGlue, 18 launches per
+  roofline     -- the dominant kernel by total time (linear_fm_kernel<64>, LightGlue's linear layers, 55 launches per
                   step) priced against the gfx950 FP32 matrix peak, from HIP events recorded on the engine's own
-                  stream around every launch during the timed steps; `other_kernels` prices the conv kernel too;
+                  stream around every launch during sampled timed steps; `other_kernels` prices the attention and
+                  the pooled conv kernels the same way;
   cpu_baseline -- the CPU oracle ("port" of the reference's LibTorch-CPU path) timed on this host's cores on a
                   bounded sample of the same frames (rank 0, N = 1 only).
+A default N = 1 run adds, measured AFTER the timed region and never part of `value`: lg_gemm_bf16x3 / lg_gemm_bf16x3_all
+(the same workload with LightGlue's matrix products in the opt-in bf16x3 arithmetic, dani_lg_set_gemm) and `device`
+(the card's facts next to the peaks used).
 """
 import argparse
 import json
