@@ -9,7 +9,8 @@
 // chain is of the order of the f32 rounding itself; the ORDER of the additions differs from the canonical order of
 // the oracle, which is why this is an option of the LightGlue stage (tolerance 1e-3 on the scores) and never of
 // SuperPoint / YOLO (bit-exact).  Six bf16 MFMAs per 16 k replace eight f32 MFMAs per 16 k at a quarter of the
-// cycles each: the layer stops being MFMA-bound and runs at what the load path gives.
+// cycles each: the layer stops being MFMA-bound; measured 1.3-1.4x per layer (operand split on the VALU and fragment
+// traffic take over).
 //
 // Same interface, token layout, epilogues (rotary, alpha, residual) and 1-D XCD-aware grid as linear_fm_kernel<64>.
 // Workgroup = 64 outputs x 64 tokens, waves 2x2 of 32x32.  X is read as f32, split on the VALU while staging and kept
@@ -31,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct LinX3Args {
   const float* x0; const float* x1; int K0, K1;
-  const u32x4* w;   // [otile][K/16][half][plane][lane] fragments of 8 bf16, see pack_linear_x3 (host_logic.cpp)
+  const u32x4* w;   // [otile][K/16][half][plane][lane] fragments of 8 bf16, see pack_linear_x3 below
   const float* bias;
   float* y; const float* res; const float* cosb; const float* sinb;
   int OUT, T, ld, rot_rows;
