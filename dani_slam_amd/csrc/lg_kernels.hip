@@ -1072,15 +1072,19 @@ __global__ __launch_bounds__(256, 2) void attn_x3w_kernel(const float* Q, const 
     }
     l += ls;
     m = m_new;
+    // P^T split for both k-steps first, so that the second one's VALU work is there to be interleaved with the first
+    // step's MFMAs (one MFMA, then up to five VALU instructions: the MFMA holds the vector issue for 8 of its 32 cycles)
+    u32x4 pp[2][3];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-      u32x4 ph, pm, pl;
+    for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
         unsigned hi, mid, lo;
         x3_split2(s[8 * t + e], s[8 * t + e + 1], hi, mid, lo);
-        ph[e >> 1] = hi; pm[e >> 1] = mid; pl[e >> 1] = lo;
+        pp[t][0][e >> 1] = hi; pp[t][1][e >> 1] = mid; pp[t][2][e >> 1] = lo;
       }
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
 #pragma unroll
       for (int db = 0; db < 2; db++) {
         const int d = db * 32 + j;
@@ -1088,7 +1092,14 @@ __global__ __launch_bounds__(256, 2) void attn_x3w_kernel(const float* Q, const 
         const bf16x8 v_h = *reinterpret_cast<const bf16x8*>(vp);
         const bf16x8 v_m = *reinterpret_cast<const bf16x8*>(vp + AX_VPLANE);
         const bf16x8 v_l = *reinterpret_cast<const bf16x8*>(vp + 2 * AX_VPLANE);
-        x3_mfma6(o[db], v_h, v_m, v_l, __builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl));
+        x3_mfma6(o[db], v_h, v_m, v_l, __builtin_bit_cast(bf16x8, pp[t][0]), __builtin_bit_cast(bf16x8, pp[t][1]), __builtin_bit_cast(bf16x8, pp[t][2]));
+      }
+      if (t == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+        }
       }
     }
   }
