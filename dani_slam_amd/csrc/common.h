@@ -90,8 +90,9 @@ inline ConvVariant conv_small_variant(ConvVariant v) {
 // conv1a: u8 image -> 64-channel padded planar, fused /255 + 3x3 conv + bias + ReLU (VALU kernel).
 void launch_conv1a(const uint8_t* img, int B, int H, int W, int stride, size_t img_frame_stride, const float* w /*64*9*/,
                    const float* bias /*64*/, const ActDesc& out, hipStream_t s);
-void launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s);
-void launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s);
+// false = shape outside the kernel's 32-bit addressing contract: nothing was launched (DANI_ERR_UNSUPPORTED upstream)
+bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s);
+bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s);
 const char* conv_kernel_name(ConvVariant v);
 
 // semi [B][65(+pad)][..] padded planar -> prob [B][PH][PW] dense
@@ -144,12 +145,12 @@ struct LgSet {
 };
 // bf16x3 variant (lg_x3.hip): same function and layout, contraction on the bf16 matrix cores at f32 accuracy.  w_x3 is
 // the weight split by pack_linear_x3 (x3_packed_u16(out, in) 16-bit words); OUT, K0, K1 multiples of 64.
-void launch_linear_x3(const float* x0, int K0, const float* x1, int K1, const void* w_x3, const float* bias_packed,
+bool launch_linear_x3(const float* x0, int K0, const float* x1, int K1, const void* w_x3, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s);
 size_t x3_packed_u16(int out, int in);
 void pack_linear_x3(const float* w_row_major, int out, int in, uint16_t* dst);
-void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
+bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s);
 void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s);
@@ -183,7 +184,8 @@ int yolo_dynamic_areas(const float* dets6, int n, int cols, int rows, const char
 // ---- host logic --------------------------------------------------------------------------------
 struct HostKey { float x, y, r; };
 // DistributeOctTree (reference src/SPextractor.cpp:405-629); returns indices into `keys`, in list order.
-void distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY, int maxY, int N,
+// false: the region is one the reference cannot process either (round(width / height) < 1, or a key outside it)
+bool distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY, int maxY, int N,
                         std::vector<int>& out_idx);
 int cell_grid(int width, int height, std::vector<CellRect>& cells);
 // hand-off formats (host_logic.cpp)

@@ -235,7 +235,7 @@ using CfgRow32nSilu      = Cfg<3, 1, 1, 32, 2, 8, ACT_SILU, false, 1>;
 using CfgConv1Row32nSilu = Cfg<1, 1, 1, 32, 2, 32, ACT_SILU, false, 1>;
 
 template <class C>
-static void launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
+static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
   ConvArgs a;
   a.in = io.in; a.w = L.w_packed; a.bias = L.bias_packed; a.out = io.out; a.res = io.res;
   a.Cin = L.CinPad; a.Cout = L.Cout; a.H = io.H; a.W = io.W;
@@ -245,46 +245,46 @@ static void launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   a.tiles_y = (io.H + C::TH - 1) / C::TH;
   a.cout_tiles = L.cout_tiles;
   a.nchunks = L.CinPad / C::CC;
-  if ((size_t)(L.cout_tiles * C::NCO + 8) * io.oHp * io.oWp >= ((size_t)1 << 30)) {   // 32-bit byte offsets inside a frame (epilogue)
-    fprintf(stderr, "conv launch: output tensor of %d x %d x %d floats per frame is too large\n", L.Cout, io.oHp, io.oWp);
-    abort();
-  }
+  // 32-bit byte offsets inside a frame (epilogue): refused, not launched; the engine reports DANI_ERR_UNSUPPORTED
+  if ((size_t)(L.cout_tiles * C::NCO + 8) * io.oHp * io.oWp >= ((size_t)1 << 30)) return false;
   const int grid = B * a.tiles_x * a.tiles_y * a.cout_tiles;
   hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), 0, s, a);
+  return true;
 }
 
-void launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
+bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
   switch (L.variant) {
-    case CONV3_ROW32_RELU: launch_cfg<CfgRow32Relu>(L, io, B, s); break;
-    case CONV3_ROW32_RELU_POOL: launch_cfg<CfgRow32ReluPool>(L, io, B, s); break;
-    case CONV3_BLK16_RELU: launch_cfg<CfgBlk16Relu>(L, io, B, s); break;
-    case CONV1_BLK16_LINEAR: launch_cfg<CfgConv1Blk16>(L, io, B, s); break;
-    case CONV6S2_ROW32_SILU: launch_cfg<CfgStem6Row32>(L, io, B, s); break;
-    case CONV3S2_ROW32_SILU: launch_cfg<CfgS2Row32Silu>(L, io, B, s); break;
-    case CONV3S2_BLK16_SILU: launch_cfg<CfgS2Blk16Silu>(L, io, B, s); break;
-    case CONV3_ROW32_SILU: launch_cfg<CfgRow32Silu>(L, io, B, s); break;
-    case CONV3_BLK16_SILU: launch_cfg<CfgBlk16Silu>(L, io, B, s); break;
-    case CONV1_ROW32_SILU: launch_cfg<CfgConv1Row32Silu>(L, io, B, s); break;
-    case CONV1_BLK16_SILU: launch_cfg<CfgConv1Blk16Silu>(L, io, B, s); break;
-    case CONV3_BLK16S_RELU: launch_cfg<CfgBlk16sRelu>(L, io, B, s); break;
-    case CONV1_BLK16S_LINEAR: launch_cfg<CfgConv1Blk16s>(L, io, B, s); break;
-    case CONV3_BLK16S_SILU: launch_cfg<CfgBlk16sSilu>(L, io, B, s); break;
-    case CONV3S2_BLK16S_SILU: launch_cfg<CfgS2Blk16sSilu>(L, io, B, s); break;
-    case CONV1_BLK16S_SILU: launch_cfg<CfgConv1Blk16sSilu>(L, io, B, s); break;
-    case CONV6S2_ROW32N_SILU: launch_cfg<CfgStem6Row32n>(L, io, B, s); break;
-    case CONV3_ROW32N_SILU: launch_cfg<CfgRow32nSilu>(L, io, B, s); break;
-    case CONV1_ROW32N_SILU: launch_cfg<CfgConv1Row32nSilu>(L, io, B, s); break;
+    case CONV3_ROW32_RELU: return launch_cfg<CfgRow32Relu>(L, io, B, s);
+    case CONV3_ROW32_RELU_POOL: return launch_cfg<CfgRow32ReluPool>(L, io, B, s);
+    case CONV3_BLK16_RELU: return launch_cfg<CfgBlk16Relu>(L, io, B, s);
+    case CONV1_BLK16_LINEAR: return launch_cfg<CfgConv1Blk16>(L, io, B, s);
+    case CONV6S2_ROW32_SILU: return launch_cfg<CfgStem6Row32>(L, io, B, s);
+    case CONV3S2_ROW32_SILU: return launch_cfg<CfgS2Row32Silu>(L, io, B, s);
+    case CONV3S2_BLK16_SILU: return launch_cfg<CfgS2Blk16Silu>(L, io, B, s);
+    case CONV3_ROW32_SILU: return launch_cfg<CfgRow32Silu>(L, io, B, s);
+    case CONV3_BLK16_SILU: return launch_cfg<CfgBlk16Silu>(L, io, B, s);
+    case CONV1_ROW32_SILU: return launch_cfg<CfgConv1Row32Silu>(L, io, B, s);
+    case CONV1_BLK16_SILU: return launch_cfg<CfgConv1Blk16Silu>(L, io, B, s);
+    case CONV3_BLK16S_RELU: return launch_cfg<CfgBlk16sRelu>(L, io, B, s);
+    case CONV1_BLK16S_LINEAR: return launch_cfg<CfgConv1Blk16s>(L, io, B, s);
+    case CONV3_BLK16S_SILU: return launch_cfg<CfgBlk16sSilu>(L, io, B, s);
+    case CONV3S2_BLK16S_SILU: return launch_cfg<CfgS2Blk16sSilu>(L, io, B, s);
+    case CONV1_BLK16S_SILU: return launch_cfg<CfgConv1Blk16sSilu>(L, io, B, s);
+    case CONV6S2_ROW32N_SILU: return launch_cfg<CfgStem6Row32n>(L, io, B, s);
+    case CONV3_ROW32N_SILU: return launch_cfg<CfgRow32nSilu>(L, io, B, s);
+    case CONV1_ROW32N_SILU: return launch_cfg<CfgConv1Row32nSilu>(L, io, B, s);
   }
+  return false;
 }
 
 // SuperPoint convenience form: whole tensors in the standard padded planar layout
-void launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s) {
+bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s) {
   ConvIO io;
   io.in = in.p; io.out = out.p; io.res = nullptr;
   io.H = in.H; io.W = in.W;   // stride-1 layers: conv output dims == input dims (pooling happens in the epilogue)
   io.iHp = in.Hp; io.iWp = in.Wp; io.ipady = in.pady; io.oHp = out.Hp; io.oWp = out.Wp; io.opady = out.pady;
   io.in_fs = in.frame_stride(); io.out_fs = out.frame_stride(); io.res_fs = 0;
-  launch_conv_io(L, io, B, s);
+  return launch_conv_io(L, io, B, s);
 }
 
 const char* conv_kernel_name(ConvVariant v) {

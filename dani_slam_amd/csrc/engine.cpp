@@ -12,6 +12,12 @@ namespace dani {
 namespace eng {
 
 thread_local std::string g_create_error;
+// Error text is kept per calling thread (several host threads share one engine: stereo extractors, mapping threads):
+// the message of this thread's last failed call, tagged with the engine it belongs to; e->err (under err_mu) keeps the
+// engine's most recent one for threads that have none of their own.
+thread_local std::string t_err;
+thread_local const dani_engine* t_err_engine = nullptr;
+thread_local std::string t_err_copy;
 
 int fail(dani_engine* e, int code, const char* fmt, ...) {
   char buf[512];
@@ -19,7 +25,11 @@ int fail(dani_engine* e, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
-  if (e) e->err = buf; else g_create_error = buf;
+  if (e) {
+    t_err = buf; t_err_engine = e;
+    std::lock_guard<std::mutex> lk(e->err_mu);
+    e->err = buf;
+  } else g_create_error = buf;
   return code;
 }
 
@@ -46,15 +56,19 @@ hipError_t create_priority_stream(hipStream_t* s) {
   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
 }
 
+// A free context of the pool; when all n_contexts are in use the caller WAITS for one (calls are short and always
+// release): more concurrent callers than contexts is a throughput matter, never an error.
 Context* acquire(dani_engine* e) {
-  std::lock_guard<std::mutex> lk(e->mu);
-  for (Context* c : e->ctxs)
-    if (!c->busy) { c->busy = true; return c; }
-  return nullptr;
+  std::unique_lock<std::mutex> lk(e->mu);
+  for (;;) {
+    for (Context* c : e->ctxs)
+      if (!c->busy) { c->busy = true; return c; }
+    e->ctx_free.wait(lk);
+  }
 }
 void release(dani_engine* e, Context* c) {
-  std::lock_guard<std::mutex> lk(e->mu);
-  c->busy = false;
+  { std::lock_guard<std::mutex> lk(e->mu); c->busy = false; }
+  e->ctx_free.notify_one();
 }
 
 int dev_alloc(dani_engine* e, Context* c, void** p, size_t bytes, bool zero) {
@@ -88,7 +102,13 @@ extern "C" {
 
 const char* dani_version(void) { return "dani-frontend-hip 0.1 (gfx950)"; }
 
-const char* dani_last_error(const dani_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+const char* dani_last_error(const dani_engine* e) {
+  if (!e) return g_create_error.c_str();
+  if (t_err_engine == e) return t_err.c_str();          // this thread's own last failure on this engine
+  std::lock_guard<std::mutex> lk(const_cast<dani_engine*>(e)->err_mu);
+  t_err_copy = e->err;                                   // another thread's: a private copy, never a pointer into shared state
+  return t_err_copy.c_str();
+}
 
 int dani_engine_create(const dani_config* cfg, dani_engine** out) {
   if (!cfg || !out) return fail(nullptr, DANI_ERR_INVALID, "null argument");
@@ -147,7 +167,11 @@ void dani_engine_destroy(dani_engine* e) {
 
 int dani_set_tensor(dani_engine* e, const char* name, const float* data, int64_t count) {
   if (!e || !name || !data || count <= 0) return fail(e, DANI_ERR_INVALID, "bad dani_set_tensor argument");
-  e->tensors[name].assign(data, data + count);
+  try {
+    e->tensors[name].assign(data, data + count);
+  } catch (const std::exception&) {
+    return fail(e, DANI_ERR_INVALID, "out of host memory for tensor %s (%lld floats)", name, (long long)count);
+  }
   e->finalized = false;
   return DANI_OK;
 }
@@ -160,16 +184,20 @@ int dani_load_weights_file(dani_engine* e, const char* path) {
   char magic[4];
   uint32_t n = 0;
   bool ok = fread(magic, 1, 4, f) == 4 && memcmp(magic, "DSW1", 4) == 0 && fread(&n, 4, 1, f) == 1;
-  for (uint32_t i = 0; ok && i < n; i++) {
-    uint32_t nl = 0;
-    uint64_t cnt = 0;
-    ok = fread(&nl, 4, 1, f) == 1 && nl < 256;
-    std::string name(nl, '\0');
-    ok = ok && fread(&name[0], 1, nl, f) == nl && fread(&cnt, 8, 1, f) == 1 && cnt < (1ull << 28);
-    if (!ok) break;
-    std::vector<float> v(cnt);
-    ok = fread(v.data(), 4, cnt, f) == cnt;
-    if (ok) e->tensors[name].swap(v);
+  try {   // no exception crosses the ABI: a malformed or huge file is an error code, not a std::bad_alloc
+    for (uint32_t i = 0; ok && i < n; i++) {
+      uint32_t nl = 0;
+      uint64_t cnt = 0;
+      if (fread(&nl, 4, 1, f) != 1 || nl == 0 || nl >= 256) { ok = false; break; }   // checked BEFORE anything is sized by it
+      std::string name(nl, '\0');
+      ok = fread(&name[0], 1, nl, f) == nl && fread(&cnt, 8, 1, f) == 1 && cnt > 0 && cnt < (1ull << 28);
+      if (!ok) break;
+      std::vector<float> v(cnt);
+      ok = fread(v.data(), 4, cnt, f) == cnt;
+      if (ok) e->tensors[name].swap(v);
+    }
+  } catch (const std::exception&) {
+    ok = false;
   }
   fclose(f);
   if (!ok) return fail(e, DANI_ERR_WEIGHTS, "malformed weight file %s", path);

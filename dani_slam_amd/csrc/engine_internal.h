@@ -63,6 +63,9 @@ struct Context {
   float* d_desc_all = nullptr;
   int prev_n = 0;            // keypoints of the cached previous frame (slot 0)
   float* d_kxy = nullptr;
+  float* d_kimg_all = nullptr;   // [B + 1][kcap][2] keypoint->pt in image coordinates, output order (slot 0: previous frame)
+  float* d_kimg = nullptr;       // slot 1
+  float* h_kimg = nullptr;       // pinned staging of slots 1..B
   int32_t* d_nk = nullptr;
   float* d_sampled = nullptr;
   float* d_descout = nullptr;
@@ -104,8 +107,10 @@ struct dani_engine {
   std::vector<void*> weight_allocs;
   std::vector<dani::eng::Context*> ctxs;
   std::mutex mu;
-  bool profiling = false;
-  int lg_gemm = 0;   // DANI_LG_GEMM_*: 0 = f32 MFMA in the canonical order, 1 = bf16x3 split linears (lg_x3.hip), 2 = + attention
+  std::mutex err_mu;                    // guards err (per-thread copies are handed out, engine.cpp)
+  std::condition_variable ctx_free;     // signalled by release(): acquire() waits on it under mu
+  std::atomic<bool> profiling{false};   // read by concurrent calls
+  std::atomic<int> lg_gemm{0};   // DANI_LG_GEMM_*: 0 = f32 MFMA in the canonical order, 1 = bf16x3 split linears (lg_x3.hip), 2 = + attention
   dani::eng::LgWeights* lgw = nullptr;             // packed LightGlue / YOLO weights (owned; device buffers are in weight_allocs)
   dani::eng::YoloWeights* yw = nullptr;
   std::map<int, dani::eng::SeqState*> seqs;        // dani_frontend_batch sequences (own context + cached previous frame), under mu

@@ -175,7 +175,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   auto enqueue_cache = [&] {   // the last frame's features become the next call's predecessor (slot 0 of the slabs)
     if (cache_enqueued) return;
     cache_enqueued = true;
-    (void)hipMemcpyAsync(c->d_kxy_all, c->d_kxy + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(c->d_kimg_all, c->d_kimg + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream);
     (void)hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream);
   };
   std::function<void()> move_desc = [&] {
@@ -193,7 +193,9 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     const float sz[2] = {(float)W, (float)H};
     LgCall lg_call;
     lg_call.ctx = c; lg_call.overlap = &move_desc;
-    rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kxy_all, c->d_desc_all, n0.data(), c->d_kxy, c->d_descout, n1.data(), sz, sz,
+    // keypoints as the reference hands them to matchDescriptors: mvKeys (scaled by the level's factor, mono / stereo
+    // partition order, src/SPextractor.cpp:164-216) next to the un-permuted descriptor rows (:159)
+    rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kimg_all, c->d_desc_all, n0.data(), c->d_kimg, c->d_descout, n1.data(), sz, sz,
                              p->lg_threshold, matches, scores, match_cap, k_out);
     if (rc) { move_desc(); (void)hipStreamSynchronize(c->stream); return rc; }
   }

@@ -137,10 +137,14 @@ struct QTree {
 
 }  // namespace
 
-void distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY, int maxY, int N,
+// Returns false (nothing written) where the reference itself has undefined behaviour: nIni = round(width / height) = 0
+// for portrait regions (width / height < 0.5: hX = inf and vpIniNodes is empty, src/SPextractor.cpp:410-428), or a key
+// whose x lies outside [0, maxX - minX) (vpIniNodes[kp.pt.x / hX] out of range, :433).
+bool distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY, int maxY, int N,
                         std::vector<int>& out_idx) {
   out_idx.clear();
-  if (n <= 0) return;
+  if (n <= 0) return true;
+  if (maxX <= minX || maxY <= minY) return false;
   // per-thread scratch kept between calls: ~0.8 MB of node and key-record storage; allocating it per call (mmap +
   // first-touch page faults) cost as much as the algorithm
   thread_local QTree t;
@@ -150,12 +154,17 @@ void distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY
   t.nodes.reserve(8 * (size_t)std::max(N, 64) + 64);
   t.pool.reserve((size_t)n * 12);
   const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+  if (nIni < 1) return false;
   const float hX = static_cast<float>(maxX - minX) / nIni;
   // initial nodes + assignment (stable per node)
   thread_local std::vector<int> which;
   which.resize(n);
   std::vector<int> cnt(std::max(nIni, 1), 0);
-  for (int i = 0; i < n; i++) { which[i] = (int)(keys[i].x / hX); cnt[which[i]]++; }
+  for (int i = 0; i < n; i++) {
+    const float q = keys[i].x / hX;
+    if (!(q >= 0.0f) || !(q < (float)nIni)) return false;
+    which[i] = (int)q; cnt[which[i]]++;
+  }
   std::vector<int> start(nIni + 1, 0);
   for (int i = 0; i < nIni; i++) start[i + 1] = start[i] + cnt[i];
   t.pool.resize(n);
@@ -236,6 +245,7 @@ void distribute_octtree(const HostKey* keys, int n, int minX, int maxX, int minY
     }
     out_idx.push_back(best);
   }
+  return true;
 }
 
 }  // namespace dani

@@ -248,7 +248,8 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
 // the 9-layer forward + assignment statistics on stream s; the sets in L->d_sets point at their token-major inputs
 struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T; };   // T = all main regions + the tail region
 
-void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof, int gemm) {
+// false: a linear layer refused its shape (nothing of that layer was launched)
+bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof, int gemm) {
   const int ld = L->ld, nsets = sh.nsets, max_n = sh.max_n, T = sh.T, max_np = round_up(max_n, 32);
   if (prof && !L->aev_ready) {
     for (auto& ev : L->aev) (void)hipEventCreate(&ev);
@@ -263,10 +264,11 @@ void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
   };
   launch_desc_to_fm(L->d_sets, nsets, sh.max_span, L->x, ld, s);
   launch_posenc(L->d_sets, nsets, sh.max_span, W->wr, L->cosb, L->sinb, ld, s);
+  bool ok = true;
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
-    if (gemm != DANI_LG_GEMM_F32) launch_linear_x3(x0, K0, x1, K1, l.w3, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
-    else launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s);
+    if (gemm != DANI_LG_GEMM_F32) ok = launch_linear_x3(x0, K0, x1, K1, l.w3, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s) && ok;
+    else ok = launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s) && ok;
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
   };
   for (int i = 0; i < LG_LAYERS; i++) {
@@ -291,6 +293,7 @@ void lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
   launch_sim(L->md_dense, ld, L->d_sets, nsets / 2, max_np, L->sim, L->sim_ld, pstride, s);
   launch_assignment_stats(L->sim, L->sim_ld, pstride, L->d_sets, nsets / 2, max_n, L->logsig_dense, L->lse_row, L->lse_col,
                           L->m0, L->max0, L->m1, ld, s);
+  return ok;
 }
 
 thread_local LgContext* t_last_lg = nullptr;
@@ -409,7 +412,10 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
   HIP_TRY(e, hipMemcpyAsync(L->d_sets, L->h_sets, sizeof(LgSet) * 2 * P, hipMemcpyHostToDevice, s));
   HIP_TRY(e, hipEventRecord(c->ev_lg0, s));
   const bool prof = e->profiling;
-  if (max_n > 0) lg_forward(W, L, sh, s, prof, e->lg_gemm);
+  if (max_n > 0 && !lg_forward(W, L, sh, s, prof, e->lg_gemm)) {
+    (void)hipStreamSynchronize(s);
+    return fail(e, DANI_ERR_UNSUPPORTED, "LightGlue batch of %d token columns exceeds the linear kernels' addressing range", L->ld);
+  }
   HIP_TRY(e, hipEventRecord(c->ev_lg1, s));
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemcpy2DAsync(L->h_m0, (size_t)L->ld * 4, L->m0, (size_t)L->ld * 4, (size_t)doff * 4, 3, hipMemcpyDeviceToHost, s));

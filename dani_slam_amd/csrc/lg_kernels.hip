@@ -181,13 +181,10 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
 
 int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = the 64-token tile)
 
-void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
+bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s) {
-  if (OUT % 64 || rot_rows % 64 || (size_t)OUT * ld >= ((size_t)1 << 30)) {   // contract of lin_epilogue.h
-    fprintf(stderr, "launch_linear_fm: unsupported shape OUT=%d rot_rows=%d ld=%d\n", OUT, rot_rows, ld);
-    abort();
-  }
+  if (OUT % 64 || rot_rows % 64 || (size_t)OUT * ld >= ((size_t)1 << 30)) return false;   // contract of lin_epilogue.h: refused, not launched
   LinArgs a;
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w_packed; a.bias = bias_packed; a.y = y; a.res = res;
   a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;
@@ -199,6 +196,7 @@ void launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   if (g_lin_force_tt == 256) hipLaunchKernelGGL(linear_fm_kernel<256>, grid(256), dim3(256), 0, s, a);
   else if (g_lin_force_tt == 128) hipLaunchKernelGGL(linear_fm_kernel<128>, grid(128), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(linear_fm_kernel<64>, grid(64), dim3(256), 0, s, a);
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -179,13 +179,10 @@ void pack_linear_x3(const float* w, int out, int in, uint16_t* dst) {
 
 int g_x3_force_ncb = 0;   // tuning hook of tools/probes/lin_x3_probe.hip
 
-void launch_linear_x3(const float* x0, int K0, const float* x1, int K1, const void* w_x3, const float* bias_packed,
+bool launch_linear_x3(const float* x0, int K0, const float* x1, int K1, const void* w_x3, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
                       int rot_rows, float alpha, hipStream_t s) {
-  if (OUT % 64 || rot_rows % 64 || K0 % 64 || K1 % 64 || (size_t)OUT * ld >= ((size_t)1 << 30)) {   // lin_epilogue.h; 64-row chunks
-    fprintf(stderr, "launch_linear_x3: unsupported shape OUT=%d K=%d+%d rot_rows=%d ld=%d\n", OUT, K0, K1, rot_rows, ld);
-    abort();
-  }
+  if (OUT % 64 || rot_rows % 64 || K0 % 64 || K1 % 64 || (size_t)OUT * ld >= ((size_t)1 << 30)) return false;   // lin_epilogue.h; 64-row chunks: refused
   LinX3Args a;
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = static_cast<const u32x4*>(w_x3); a.bias = bias_packed;
   a.y = y; a.res = res; a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;
@@ -195,6 +192,7 @@ void launch_linear_x3(const float* x0, int K0, const float* x1, int K1, const vo
     hipLaunchKernelGGL(linear_x3_kernel<2>, dim3((unsigned)(ntiles8 * (OUT / 128))), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL(linear_x3_kernel<1>, dim3((unsigned)(ntiles8 * ((OUT + 63) / 64))), dim3(256), 0, s, a);
+  return true;
 }
 
 }  // namespace dani

@@ -7,6 +7,8 @@
 // (host_logic.cpp) runs on the host, as it does in the reference.
 #include "engine_internal.h"
 
+#include <cmath>
+
 using namespace dani;
 using namespace dani::eng;
 
@@ -49,6 +51,10 @@ int ensure_shapes(dani_engine* e, Context* c, int W, int H, int B, int kcap, int
     L.W = lw[l]; L.H = lh[l];
     const int h = L.H, w = L.W;
     if (w < 80 || h < 80) return fail(e, DANI_ERR_UNSUPPORTED, "pyramid level %d is %dx%d: smaller than 80x80", l, w, h);
+    // DistributeOctTree starts from nIni = round(width / height) root nodes over the bordered region (src/SPextractor.cpp:410);
+    // for a portrait level nIni = 0 and the reference indexes an empty vector (:433): no defined result to reproduce
+    if ((int)std::round((float)(w - 32) / (float)(h - 32)) < 1)
+      return fail(e, DANI_ERR_UNSUPPORTED, "pyramid level %d is %dx%d: width / height below 0.5 (DistributeOctTree has no root node)", l, w, h);
     const int dims[12][2] = {{h, w}, {h / 2, w / 2}, {h / 2, w / 2}, {h / 4, w / 4}, {h / 4, w / 4}, {h / 8, w / 8},
                              {h / 8, w / 8}, {h / 8, w / 8}, {h / 8, w / 8}, {h / 8, w / 8}, {h / 8, w / 8}, {h / 8, w / 8}};
     for (int i = 0; i < 12; i++) {
@@ -95,6 +101,10 @@ int ensure_shapes(dani_engine* e, Context* c, int W, int H, int B, int kcap, int
   if ((rc = dev_alloc(e, c, (void**)&c->d_sampled, ((size_t)B * kcap * 256 + B * 256) * 4, false))) return rc;
   if ((rc = dev_alloc(e, c, (void**)&c->d_desc_all, (size_t)(B + 1) * kcap * 256 * 4, true))) return rc;
   c->d_descout = c->d_desc_all + (size_t)kcap * 256;
+  // keypoint->pt as operator() returns it (level scale applied, mono / stereo partition order): LightGlue's keypoint input
+  if ((rc = dev_alloc(e, c, (void**)&c->d_kimg_all, (size_t)(B + 1) * kcap * 2 * 4, true))) return rc;
+  c->d_kimg = c->d_kimg_all + (size_t)kcap * 2;
+  if ((rc = host_alloc(e, c, (void**)&c->h_kimg, (size_t)B * kcap * 2 * 4))) return rc;
   c->prev_n = 0;
   if ((rc = host_alloc(e, c, (void**)&c->h_kxy, ((size_t)B * kcap * 2 + nints) * 4))) return rc;
   if ((rc = host_alloc(e, c, (void**)&c->h_boxes, (size_t)(c->box_cap * 4 + B + 1) * 4))) return rc;
@@ -113,6 +123,12 @@ int check_params(dani_engine* e, int W, int H, const dani_sp_params* p) {
   if (W > e->cfg.max_width || H > e->cfg.max_height)
     return fail(e, DANI_ERR_INVALID, "image %dx%d exceeds the engine's configured maximum %dx%d", W, H, e->cfg.max_width, e->cfg.max_height);
   if (p->nfeatures <= 0 || !(p->ini_th >= 0.0f) || !(p->min_th >= 0.0f)) return fail(e, DANI_ERR_INVALID, "bad extractor params");
+  {   // the conv epilogue addresses one frame's activation tensor with 32-bit byte offsets (conv_mfma.hip, launch_cfg)
+    ActDesc a;
+    act_shape(a, 64, H, W);
+    if ((size_t)(64 + 8) * a.Hp * a.Wp >= ((size_t)1 << 30))
+      return fail(e, DANI_ERR_UNSUPPORTED, "image %dx%d: a 64-channel full-resolution activation exceeds the kernels' 4 GiB per-frame addressing range", W, H);
+  }
   return 0;
 }
 
@@ -258,7 +274,10 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       if (lprof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
       const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
       for (int i = 1; i < 12; i++) {
-        launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, s);
+        if (!launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, s)) {
+          (void)hipStreamSynchronize(s);
+          return fail(e, DANI_ERR_UNSUPPORTED, "%s at %dx%d: activation tensor exceeds the conv kernel's 32-bit addressing range", kSp[i].name, L.W, L.H);
+        }
         if (lprof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
       }
       if (l == NL - 1) HIP_TRY(e, hipEventRecord(c->ev[1], s));
@@ -333,14 +352,16 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
         }
         L.h_cand_count[b] = m;
       }
-      distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[l], sels[l]);
+      if (!distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[l], sels[l]))
+        frame_status[b] = DANI_ERR_UNSUPPORTED;   // cannot happen for levels ensure_shapes accepted and in-cell candidates
     }
     int n = 0;
     for (int l = 0; l < NL; l++) n += (int)sels[l].size();
     n_out[b] = n;
     const bool fits = n <= cap && n <= c->kcap;
-    if (!fits) frame_status[b] = DANI_ERR_CAPACITY;
+    if (!fits && frame_status[b] == DANI_OK) frame_status[b] = DANI_ERR_CAPACITY;
     float* kx = c->h_kxy + (size_t)b * c->kcap * 2;
+    float* ki = c->h_kimg + (size_t)b * c->kcap * 2;
     float* ok = kpts_xy + (size_t)b * cap * 2;
     float* orr = resp + (size_t)b * cap;
     // the mono / stereo partition runs over the levels in order (operator(), :175-213); descriptor rows keep the
@@ -361,6 +382,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
         const float fx = l ? x * scales[l] : x, fy = l ? y * scales[l] : y;              // keypoint->pt *= scale (:190-192)
         const int dst = (fx >= (float)l0 && fx <= (float)l1) ? stereoIndex-- : monoIndex++;
         ok[2 * dst] = fx; ok[2 * dst + 1] = fy; orr[dst] = keys[sel[i]].r;
+        ki[2 * dst] = fx; ki[2 * dst + 1] = fy;
         if (octave) octave[(size_t)b * cap + dst] = l;
         if (size) size[(size_t)b * cap + dst] = (float)scaledPatchSize;
       }
@@ -372,10 +394,13 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
   int status = DANI_OK;
   for (int b = 0; b < B; b++) if (frame_status[b] != DANI_OK) status = frame_status[b];
   c->ms[2] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (status != DANI_OK) return fail(e, status, "output capacity %d too small", cap);
+  if (status == DANI_ERR_CAPACITY) return fail(e, status, "output capacity %d too small", cap);
+  if (status != DANI_OK) return fail(e, status, "DistributeOctTree: region or candidate outside what the reference defines");
 
   // ---- descriptors: each level samples its own map and is normalised over its own keypoints (Q7)
   HIP_TRY(e, hipMemcpyAsync(c->d_kxy, c->h_kxy, ((size_t)MB * c->kcap * 2 + (size_t)NL * 2 * MB) * 4, hipMemcpyHostToDevice, s));
+  if (call.keep_desc_on_device)   // fused call: LightGlue reads the image-space keypoints on the device
+    HIP_TRY(e, hipMemcpyAsync(c->d_kimg, c->h_kimg, (size_t)B * c->kcap * 2 * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(e, hipEventRecord(c->ev[3], s));
   for (int l = 0; l < NL; l++) {
     const Context::Level& L = c->lv[l];
@@ -483,7 +508,8 @@ int dani_host_distribute_octtree(const float* in_xyr, int32_t n, int32_t min_x, 
                                  int32_t max_y, int32_t n_features, int32_t* out_idx, int32_t cap) {
   if (n < 0 || (n && !in_xyr) || !out_idx) return DANI_ERR_INVALID;
   std::vector<int> sel;
-  distribute_octtree(reinterpret_cast<const HostKey*>(in_xyr), n, min_x, max_x, min_y, max_y, n_features, sel);
+  if (!distribute_octtree(reinterpret_cast<const HostKey*>(in_xyr), n, min_x, max_x, min_y, max_y, n_features, sel))
+    return DANI_ERR_UNSUPPORTED;   // round(width / height) < 1, or a key outside [0, max_x - min_x): undefined in the reference
   if ((int)sel.size() > cap) return DANI_ERR_CAPACITY;
   for (size_t i = 0; i < sel.size(); i++) out_idx[i] = sel[i];
   return (int)sel.size();

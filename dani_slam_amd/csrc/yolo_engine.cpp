@@ -11,7 +11,8 @@ namespace dani {
 namespace eng {
 
 constexpr int YOLO_W = 640, YOLO_H = 380;   // cv::resize(mRGB, img, cv::Size(640, 380)), src/YoloDetect.cpp:39
-constexpr int YOLO_CAND_CAP = 15120;
+constexpr int YOLO_CAND_CAP = 15120;   // = 3 x (48*80 + 24*40 + 12*20): EVERY prediction of the 640x380 input; the decode appends each
+                                       // prediction at most once, so the candidate buffer cannot overflow at any score threshold
 constexpr int YOLO_CAND_FAST = 512;   // records per frame fetched together with the counts
 
 struct YConv { ConvLayerPlan plan; bool ready = false; };
@@ -60,6 +61,7 @@ struct YLayer { const char* name; int cin, cout, k, s; int scale; bool act; };  
 // output dims of the five pyramid levels for the fixed 380x640 network input
 constexpr int kYH[5] = {190, 95, 48, 24, 12}, kYW[5] = {320, 160, 80, 40, 20};
 static_assert(kYH[4] * kYW[4] <= 1024, "sppf_pool_kernel keeps one stride-32 plane in LDS");
+static_assert(3 * (kYH[2] * kYW[2] + kYH[3] * kYW[3] + kYH[4] * kYW[4]) == YOLO_CAND_CAP, "one candidate slot per prediction");
 
 ConvVariant yolo_variant(int k, int s, int scale, bool act) {
   const bool row32 = scale <= 1;   // 190x320 and 95x160 use 8x32 tiles, the rest 16x16
@@ -217,6 +219,7 @@ int yolo_ensure(dani_engine* e, Context* c, YoloContext** out, int B, size_t img
 // a view of channels [c0, c0+C) of buffer `a`
 struct YView { const ActDesc* a; int c0, C; };
 
+thread_local bool t_yolo_launch_ok = true;   // cleared when a conv launch refuses its shape (cannot happen at the fixed 640x380 input)
 void yolo_conv(const YoloWeights* W, const std::string& name, YView in, YView out, const YView* res, int B, hipStream_t s) {
   const ConvLayerPlan& L = W->convs.at(name).plan;
   ConvIO io;
@@ -226,7 +229,7 @@ void yolo_conv(const YoloWeights* W, const std::string& name, YView in, YView ou
   io.H = out.a->H; io.W = out.a->W;
   io.iHp = in.a->Hp; io.iWp = in.a->Wp; io.ipady = in.a->pady; io.oHp = out.a->Hp; io.oWp = out.a->Wp; io.opady = out.a->pady;
   io.in_fs = in.a->frame_stride(); io.out_fs = out.a->frame_stride(); io.res_fs = res ? res->a->frame_stride() : 0;
-  launch_conv_io(L, io, B, s);
+  if (!launch_conv_io(L, io, B, s)) t_yolo_launch_ok = false;
 }
 
 void yolo_c3(const YoloWeights* W, YoloContext* Y, const C3Def& c3, YView x, YView out, int B, hipStream_t s) {
@@ -330,7 +333,9 @@ int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, i
   }
   HIP_TRY(e, hipEventRecord(c->ev_y0, s));
   launch_yolo_preproc(dimg, B, W, H, stride, fbytes, Y->buf.at("in"), s);
+  t_yolo_launch_ok = true;
   yolo_forward(Wt, Y, B, score_thresh, s);
+  if (!t_yolo_launch_ok) { (void)hipStreamSynchronize(s); return fail(e, DANI_ERR_UNSUPPORTED, "YOLO conv launch refused its tensor shape"); }
   HIP_TRY(e, hipEventRecord(c->ev_y1, s));
   HIP_TRY(e, hipGetLastError());
   // read-back: the counts and, optimistically, the first YOLO_CAND_FAST records of every frame in one round trip;
@@ -341,7 +346,8 @@ int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, i
   HIP_TRY(e, hipStreamSynchronize(s));
   bool more = false;
   for (int b = 0; b < B; b++) {
-    if (Y->h_count[b] > YOLO_CAND_CAP) Y->h_count[b] = YOLO_CAND_CAP;
+    if (Y->h_count[b] < 0 || Y->h_count[b] > YOLO_CAND_CAP)   // more records than predictions: memory corruption, not a capacity case
+      return fail(e, DANI_ERR_HIP, "frame %d: candidate counter %d outside [0, %d]", b, Y->h_count[b], YOLO_CAND_CAP);
     if (Y->h_count[b] > YOLO_CAND_FAST) {
       more = true;
       HIP_TRY(e, hipMemcpyAsync(Y->h_cand + ((size_t)b * YOLO_CAND_CAP + YOLO_CAND_FAST) * 8, Y->cand + ((size_t)b * YOLO_CAND_CAP + YOLO_CAND_FAST) * 8,

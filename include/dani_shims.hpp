@@ -68,9 +68,11 @@ class SPextractor {
     if (_image.empty()) return -1;
     cv::Mat image = _image.getMat();
     CV_Assert(image.type() == CV_8UC1);
-    const int cap = nfeatures + 8;
-    std::vector<float> kxy(2 * cap), resp(cap), size(cap), desc((size_t)cap * 256);
-    std::vector<int32_t> octave(cap), boxes(4 * mvDynamicArea.size());
+    // DistributeOctTree may return up to 3 keypoints more than asked PER LEVEL (src/SPextractor.cpp:405-629); should a
+    // frame still need more, the engine reports the count (DANI_ERR_CAPACITY) and the call is repeated with it
+    int cap = nfeatures + 8 + 4 * nlevels;
+    std::vector<float> kxy, resp, size, desc;
+    std::vector<int32_t> octave, boxes(4 * mvDynamicArea.size());
     for (size_t i = 0; i < mvDynamicArea.size(); i++) {
       boxes[4 * i] = mvDynamicArea[i].x; boxes[4 * i + 1] = mvDynamicArea[i].y;
       boxes[4 * i + 2] = mvDynamicArea[i].width; boxes[4 * i + 3] = mvDynamicArea[i].height;
@@ -78,10 +80,24 @@ class SPextractor {
     const dani_sp_params p{nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST};
     const int32_t lap[2] = {vLappingArea[0], vLappingArea[1]};
     int32_t n = 0, mono = 0;
-    const int rc = dani_sp_extract(dani_shim::engine(), image.data, image.cols, image.rows, (int)image.step, &p,
-                                   boxes.data(), (int)mvDynamicArea.size(), lap, kxy.data(), resp.data(),
-                                   octave.data(), size.data(), desc.data(), cap, &n, &mono);
-    if (rc != DANI_OK) { std::cerr << dani_last_error(dani_shim::engine()) << std::endl; std::exit(EXIT_FAILURE); }
+    int rc = DANI_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      kxy.resize(2 * (size_t)cap); resp.resize(cap); size.resize(cap); desc.resize((size_t)cap * 256); octave.resize(cap);
+      rc = dani_sp_extract(dani_shim::engine(), image.data, image.cols, image.rows, (int)image.step, &p,
+                           boxes.data(), (int)mvDynamicArea.size(), lap, kxy.data(), resp.data(),
+                           octave.data(), size.data(), desc.data(), cap, &n, &mono);
+      if (rc != DANI_ERR_CAPACITY || n <= cap) break;
+      cap = n;
+    }
+    mLastStatus = rc;
+    if (rc != DANI_OK) {
+      // A run-time engine error on one frame must not end the SLAM process (the reference exits only when the MODEL
+      // cannot be loaded, src/SPextractor.cpp:88-91): report it and hand back what operator() returns for a frame it
+      // cannot process (-1, no keypoints, :133-134); Frame's constructors return early on an empty keypoint set.
+      std::cerr << "[SPextractor] " << dani_last_error(dani_shim::engine()) << std::endl;
+      _keypoints.clear(); _descriptors.release();
+      return -1;
+    }
     if (n == 0) _descriptors.release();
     else {
       _descriptors.create(n, 256, CV_32F);
@@ -100,6 +116,7 @@ class SPextractor {
   std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
   std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
+  int mLastStatus = DANI_OK;                 // dani_status of the last operator() call (not in the reference)
   std::vector<cv::Mat> mvImagePyramid;       // kept for source compatibility (not filled: the pyramid lives in HBM)
   std::vector<cv::Rect2i> mvDynamicArea;     // written by Tracking::GrabImageRGBD, src/Tracking.cc:1539
 
@@ -124,6 +141,7 @@ class LightGlue {
  public:
   LightGlue() { dani_shim::engine(); }
   ~LightGlue() {}
+  int mLastStatus = DANI_OK;   // dani_status of the last matchDescriptors() (not in the reference)
   // size w/h <= 0 selects the reference's size.numel()==0 branch (1 + max - min of the keypoints)
   std::vector<cv::DMatch> matchDescriptors(const std::vector<cv::KeyPoint>& keypoints1, const float* descriptors1, int n1,
                                            const std::vector<cv::KeyPoint>& keypoints2, const float* descriptors2, int n2,
@@ -140,7 +158,8 @@ class LightGlue {
     int32_t k = 0;
     const int rc = dani_lg_match(dani_shim::engine(), k1.data(), descriptors1, n1, k2.data(), descriptors2, n2,
                                  w1 > 0 ? s1 : nullptr, w2 > 0 ? s2 : nullptr, threshold, m.data(), sc.data(), cap, &k);
-    if (rc != DANI_OK) { std::cerr << dani_last_error(dani_shim::engine()) << std::endl; return out; }
+    mLastStatus = rc;
+    if (rc != DANI_OK) { std::cerr << "[LightGlue] " << dani_last_error(dani_shim::engine()) << std::endl; return out; }
     out.reserve(k);
     for (int i = 0; i < k; i++) out.emplace_back(m[2 * i], m[2 * i + 1], sc[i]);   // DMatch(queryIdx, trainIdx, distance = score)
     return out;
@@ -169,8 +188,10 @@ class YoloDetection {
     const int cap = 4096;
     std::vector<float> dets(6 * (size_t)cap);
     int32_t n = 0;
-    if (dani_yolo_detect(dani_shim::engine(), mRGB.data, mRGB.cols, mRGB.rows, (int)mRGB.step, 0.4f, 0.5f, dets.data(), cap, &n) != DANI_OK) {
-      std::cerr << dani_last_error(dani_shim::engine()) << std::endl; return true;
+    mLastStatus = dani_yolo_detect(dani_shim::engine(), mRGB.data, mRGB.cols, mRGB.rows, (int)mRGB.step, 0.4f, 0.5f, dets.data(), cap, &n);
+    if (mLastStatus != DANI_OK) {   // engine error: no boxes this frame, and the caller can see it (false + mLastStatus)
+      std::cerr << "[YoloDetection] " << dani_last_error(dani_shim::engine()) << std::endl;
+      return false;
     }
     if (n > 0) {
       std::vector<const char*> cn, dn;
@@ -186,6 +207,7 @@ class YoloDetection {
     }
     return true;
   }
+  int mLastStatus = DANI_OK;   // dani_status of the last Detect() (not in the reference)
   std::vector<cv::Rect2i> mvPersonArea = {};
   cv::Mat mRGB, mDepth;
   std::vector<std::string> mClassnames, mvDynamicNames;

@@ -53,6 +53,13 @@ int main(int argc, char** argv) {
   // empty image -> -1 (src/SPextractor.cpp:133-134)
   std::vector<cv::KeyPoint> ke; cv::Mat de;
   put_i(ex(cv::Mat(), cv::Mat(), ke, de, lap));
+  // an 8-level pyramid (Examples/Stereo-Inertial/RealSense_D435i.yaml: nFeatures 1250, nLevels 8): DistributeOctTree may
+  // overshoot by up to 3 keypoints per level, which the shim's output capacity has to cover
+  ORB_SLAM3::ORBextractor ex8(1250, 1.2f, 8, 0.015f, 0.007f);
+  std::vector<cv::KeyPoint> k8; cv::Mat d8;
+  const int mono8 = ex8(m0, cv::Mat(), k8, d8, lap);
+  put_i(ex8.mLastStatus); put_i(mono8); put_i((int)k8.size()); put_i(d8.rows);
+  for (auto& k : k8) { put_f(&k.pt.x, 1); put_f(&k.pt.y, 1); put_i(k.octave); }
   fclose(out);
   printf("shim_smoke ok: %zu + %zu keypoints, %zu matches, %zu dynamic boxes\n", k0.size(), k1.size(), matches.size(), det.mvDynamicArea.size());
   return 0;

@@ -84,6 +84,32 @@ def test_quadtree_other_aspect_ratios():
         assert np.array_equal(xyr[idx], ref)
 
 
+def test_quadtree_refuses_what_the_reference_leaves_undefined():
+    """nIni = round(width / height) = 0 for portrait regions: the reference indexes an empty vector
+    (src/SPextractor.cpp:410-433).  The product returns DANI_ERR_UNSUPPORTED instead of walking it; the same for a key
+    outside [0, maxX - minX)."""
+    rng = np.random.RandomState(3)
+    xyr = np.stack([rng.randint(0, 68, 40), rng.randint(0, 368, 40), rng.uniform(0.01, 1, 40)], 1).astype(np.float32)
+    for box in [(16, 84, 16, 384), (16, 144, 16, 464)]:                       # 100x400 and 160x480 images
+        with pytest.raises(frontend.DaniError) as ei:
+            frontend.host_distribute_octtree(xyr, *box, 100)
+        assert ei.value.code == frontend.DANI_ERR_UNSUPPORTED
+    for bad in ([[608.0, 5.0, 0.5]], [[-1.0, 5.0, 0.5]], [[float("nan"), 5.0, 0.5]]):
+        with pytest.raises(frontend.DaniError) as ei:
+            frontend.host_distribute_octtree(np.array(bad, np.float32), 16, 624, 16, 464, 100)
+        assert ei.value.code == frontend.DANI_ERR_UNSUPPORTED
+    assert len(frontend.host_distribute_octtree(np.array([[607.0, 5.0, 0.5]], np.float32), 16, 624, 16, 464, 100)) == 1
+
+
+def test_malformed_weight_file_is_an_error_code(tmp_path):
+    """dani_load_weights_file: a name length or tensor count that would size a huge allocation is rejected before
+    anything is allocated; nothing is thrown across the C ABI.  (Needs an engine handle, so only the NULL-engine
+    argument check runs without a GPU.)"""
+    lib = frontend.load_library()
+    lib.dani_load_weights_file.restype = ctypes.c_int
+    assert lib.dani_load_weights_file(None, b"/nonexistent") == frontend.DANI_ERR_INVALID
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """On a machine without an MI355X the engine must refuse to exist (there is no CPU compute path)."""
     import torch

@@ -65,6 +65,11 @@ def test_cpp_shims_match_ctypes_path(tmp_path, sp_weights):
     nm = geti()
     matches = [(geti(), geti(), float(getf(1)[0])) for _ in range(nm)]
     empty_rc = geti()
+    st8, mono8, n8, rows8 = geti(), geti(), geti(), geti()
+    k8 = []
+    for _ in range(n8):
+        x, y = getf(2)
+        k8.append((x, y, geti()))
     assert pos == len(buf) and ok == 1 and empty_rc == -1
 
     # the same calls through the ctypes mirror
@@ -83,4 +88,9 @@ def test_cpp_shims_match_ctypes_path(tmp_path, sp_weights):
     m, s = e.lg_match(r0["kpts"], r0["desc"], r1["kpts"], r1["desc"], (640.0, 480.0), (640.0, 480.0), 0.05)
     assert [(a, b) for a, b, _ in matches] == [tuple(x) for x in m.tolist()]
     np.testing.assert_allclose([c for _, _, c in matches], s, rtol=0, atol=1e-6)
+    # the 8-level call: status OK (capacity covers the per-level overshoot), same keypoints as the ctypes path
+    r8 = e.sp_extract_batch(g0, nfeatures=1250, nlevels=8)[0]
+    assert st8 == 0 and n8 == rows8 == len(r8["kpts"]) and n8 >= 1250 and mono8 == r8["mono_index"]
+    assert np.array_equal(np.array([[k[0], k[1]] for k in k8], np.float32), r8["kpts"])
+    assert [k[2] for k in k8] == r8["octave"].tolist() and max(k[2] for k in k8) == 7
     e.close()

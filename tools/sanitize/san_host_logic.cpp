@@ -13,6 +13,15 @@ int main() {
   std::vector<int> out;
   for (int N : {1, 5, 100, 1024, 3000, 5000}) for (int n : {0, 1, 2, 50, 3277}) { distribute_octtree(keys.data(), n, 16, 624, 16, 464, N, out); }
   printf("quadtree ok %zu\n", out.size());
+  // portrait regions (round(width / height) = 0: the reference indexes an empty vector, src/SPextractor.cpp:410-433) and
+  // keys outside the region must be refused, not walked
+  bool refused = !distribute_octtree(keys.data(), 50, 16, 84, 16, 384, 100, out) && out.empty();      // 100x400 image
+  refused = refused && !distribute_octtree(keys.data(), 50, 16, 144, 16, 464, 100, out);              // 160x480 image
+  HostKey bad[3] = {{10.f, 10.f, 0.5f}, {608.f, 10.f, 0.5f}, {-1.f, 3.f, 0.2f}};
+  refused = refused && !distribute_octtree(bad, 2, 16, 624, 16, 464, 100, out) && !distribute_octtree(bad + 2, 1, 16, 624, 16, 464, 100, out);
+  refused = refused && !distribute_octtree(bad, 1, 16, 16, 16, 464, 100, out);                        // empty region
+  if (!refused) { printf("portrait / out-of-range keys were not refused\n"); return 1; }
+  printf("portrait ok\n");
   std::mt19937 rng(1);
   std::uniform_real_distribution<float> ux(-10, 650), uy(-10, 490);
   std::vector<float> k(2 * 1025); for (int i = 0; i < 1025; i++) { k[2*i] = ux(rng); k[2*i+1] = uy(rng); }

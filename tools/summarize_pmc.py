@@ -44,8 +44,10 @@ for k, d in agg.items():
         e["kernel_cycles_per_xcd"] = cyc
         if "SQ_VALU_MFMA_BUSY_CYCLES" in e:
             e["mfma_busy_frac"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc
-        if "avg_duration_ns_profiled" in e:
-            e["effective_clock_ghz"] = cyc / e["avg_duration_ns_profiled"]
+        # GRBM_GUI_ACTIVE / 8 / duration is only a clock for dispatches of >= 0.3 ms (MI355X_MICROARCH.md, DVFS
+        # give-back: the quotient reads high on shorter ones), so it is reported for those alone
+        if e.get("avg_duration_ns_profiled", 0) >= 300000:
+            e["effective_clock_ghz_long_dispatch"] = cyc / e["avg_duration_ns_profiled"]
     if "FETCH_SIZE" in e or "WRITE_SIZE" in e:
         e["hbm_bytes_per_launch"] = 2 * e.get("FETCH_SIZE", 0) * 1024 + e.get("WRITE_SIZE", 0) * 1024
     out[k] = e
@@ -55,7 +57,7 @@ for k, e in out.items():
     if dom in k:
         json.dump({"kernel": k, "hbm_bytes_per_launch": round(e.get("hbm_bytes_per_launch", 0)),
                    "source": f"profiles/{tag}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, KiB->B, avg over the kernel's launches)",
-                   "mfma_busy_frac": e.get("mfma_busy_frac"), "effective_clock_ghz": e.get("effective_clock_ghz")},
+                   "mfma_busy_frac": e.get("mfma_busy_frac")},
                   open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-        print("dominant:", k, json.dumps({x: e[x] for x in e if x in ("mfma_busy_frac", "effective_clock_ghz", "hbm_bytes_per_launch", "avg_duration_ns_profiled")}))
+        print("dominant:", k, json.dumps({x: e[x] for x in e if x in ("mfma_busy_frac", "hbm_bytes_per_launch", "avg_duration_ns_profiled")}))
 print("wrote profiles/%s_pmc_summary.json" % tag)
