@@ -4,23 +4,28 @@
 A "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
 FRAMES_PER_GPU (8 = BASELINE config #4's 64 frames / 8 GPUs) 640x480 frames per GPU through dani_frontend_batch,
 i.e. the full front-end of BASELINE config #4: YOLOv5s dynamic-object boxes -> SuperPoint extraction (1024
-keypoints, boxes culled) -> LightGlue match of every frame against its predecessor.  Frames are batch-sharded over
-ranks with no data-path collective (weak scaling).
+keypoints, boxes culled) -> LightGlue match of every frame against its predecessor.  The frames are consecutive frames
+of ONE synthetic camera trajectory (2 degrees of rotation + 8 px per frame; dani_slam_amd/synth.py
+sequence_frame), batch-sharded over ranks with no data-path collective (weak scaling); the
+synthetic SuperPoint weights carry the centred descriptor head, so LightGlue finds ~100 matches per consecutive pair.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel by total time (linear_fm_kernel<64>, LightGlue's linear layers, 55 launches per
-                  step) priced against the gfx950 FP32 matrix peak, from HIP events recorded on the engine's own
-                  stream around every launch during sampled timed steps; `other_kernels` prices the attention and
-                  the pooled conv kernels the same way;
-  cpu_baseline -- the CPU oracle ("port" of the reference's LibTorch-CPU path) timed on this host's cores on a
-                  bounded sample of the same frames (rank 0, N = 1 only).
-A default N = 1 run adds, measured AFTER the timed region and never part of `value`: lg_gemm_bf16x3 / lg_gemm_bf16x3_all
-(the same workload with LightGlue's matrix products in the opt-in bf16x3 arithmetic, dani_lg_set_gemm) and `device`
-(the card's facts next to the peaks used).
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
+  roofline      -- the dominant kernel by total time (linear_fm_kernel<64>, LightGlue's linear layers, 55 launches per
+                   step) priced against the gfx950 FP32 matrix peak, from HIP events recorded on the engine's own
+                   stream around every launch during sampled timed steps; `other_kernels` prices the attention and
+                   the pooled conv kernels the same way; `traffic` is the PMC figure committed under profiles/;
+  cpu_baseline  -- the reference-faithful CPU path (ATen-CPU operators for the three networks + the restated host logic,
+                   oracle/aten_ref.py frontend_frame) timed on this host's cores on a bounded sample of the same frames,
+                   single-thread and all cores, per stage (rank 0, N = 1 only);
+  step_ms       -- median / p10 / p90 of the per-step wall times of the timed region (rank 0);
+  latency_b1_ms -- BASELINE configs #2 (SuperPoint extract, one frame per call) and #3 (SuperPoint x 2 + one LightGlue
+                   pair per call), measured after the timed region (N = 1 only); `--config 2|3` makes one of them the run.
+A default N = 1 run also adds lg_gemm_bf16x3 / lg_gemm_bf16x3_all (the same workload with LightGlue's matrix products
+in the opt-in bf16x3 arithmetic), measured AFTER the timed region and never part of `value`.
 """
 import argparse
 import json
@@ -34,8 +39,6 @@ sys.path.insert(0, ROOT)
 FRAMES_PER_GPU = 8
 W, H = 640, 480
 NFEATURES = 1024
-# algorithmic MAC per 640x480 frame and layer: M*N*K of the implicit GEMM
-LAYER_GMAC = [0.177, 11.325, 2.831, 2.831, 1.416, 2.831, 0.708, 0.708, 1.416, 0.080, 1.416, 0.315]
 SP_GFLOP_PER_FRAME = 52.10
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 DOMINANT_LAYERS = (1, 3, 5)       # conv1b, conv2b, conv3b: conv_mfma_kernel<Cfg<3,1,32,2,8,true,true>>
@@ -50,37 +53,60 @@ def exact_layer_flops(li, B):
     return 2.0 * h * w * cout * cin * k * k * B
 
 
+def pct(xs, q):
+    import numpy as np
+    return round(float(np.percentile(np.asarray(xs, np.float64), q)), 4) if len(xs) else None
+
+
 def cpu_baseline(gray, bgr, weights):
-    """Time the oracles (CPU port of the reference's LibTorch-CPU path) on a bounded sample of the same frames:
-    YOLO detect -> SuperPoint extract with the boxes -> LightGlue vs the previous frame."""
-    from oracle import lg_oracle, oracle, yolo_oracle
-    cores = len(os.sched_getaffinity(0))
+    """The reference's CPU path restated: LibTorch's own ATen-CPU kernels for SuperPoint::forward, the LightGlue and
+    YOLOv5s forwards (the reference runs all three on LibTorch-CPU: src/SPextractor.cpp:230, src/LightGlue.cpp:10,
+    src/YoloDetect.cpp:9) + the literal restatement of its host logic (per-cell getKeyPoints / NMS2 loop, quadtree, box
+    logic), one frame at a time as the reference does (batch 1).  Timed on a bounded sample of the bench frames with one
+    thread and with all host cores."""
+    import torch
+    from oracle import aten_ref, oracle
     oracle.lib()
-    n = 0
-    prev = None
-    t0 = time.perf_counter()
-    while True:
-        i = n % len(gray)
-        ok, dets, dyn, dmap = yolo_oracle.detect(weights, bgr[i])
-        cur = oracle.sp_extract(gray[i], weights, nfeatures=NFEATURES, boxes=dyn)
-        if prev is not None:
-            lg_oracle.match_descriptors(weights, prev["kpts"], prev["desc"], cur["kpts"], cur["desc"], (W, H), (W, H), 0.05)
-        prev = cur
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > 20.0 or n >= 8:
-            break
-    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 640x480 frames through the oracle composition yolo_oracle.detect -> "
-                      f"oracle.sp_extract -> lg_oracle.match_descriptors ({n - 1} pairs) on {cores} host cores "
-                      f"(OpenMP C for the convolutions, numpy/BLAS for LightGlue), {dt:.1f} s"}
+    cores = len(os.sched_getaffinity(0))
+    tw = aten_ref.torch_weights(weights)
+    runs = {}
+    for label, nthreads, budget_s, max_frames in (("all_cores", cores, 12.0, 48), ("one_thread", 1, 12.0, 8)):
+        torch.set_num_threads(nthreads)
+        aten_ref.frontend_frame(tw, gray[0], bgr[0], None, nfeatures=NFEATURES)      # untimed: first-call set-up of the ATen kernels
+        stages, prev, n = {}, None, 0
+        t0 = time.perf_counter()
+        while True:
+            i = n % len(gray)
+            prev = aten_ref.frontend_frame(tw, gray[i], bgr[i], prev, nfeatures=NFEATURES, stages=stages)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= max_frames:
+                break
+        runs[label] = {"frames_per_s": round(n / dt, 4), "threads": nthreads, "frames": n, "seconds": round(dt, 2),
+                       "matches_last_pair": int(len(prev.get("matches", []))),
+                       "stage_ms_per_frame": {k: round(v / n * 1e3, 2) for k, v in stages.items()}}
+    torch.set_num_threads(cores)
+    best = runs["all_cores"]
+    return {"value": best["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "flavour": f"ATen-CPU op sequence of the reference (torch {torch.__version__}, torch.get_num_threads() = {cores}) + "
+                       "restated host logic in C (the reference's own 204-cell loop indexes tensors element by element and is "
+                       "slower than this); the reference's sources need OpenCV and cannot be built on this box",
+            "sample": f"{best['frames']} consecutive 640x480 frames of the bench sequence, one at a time (batch 1, as the "
+                      f"reference): YOLOv5s + NMS + box logic -> SuperPoint forward + 204-cell loop + quadtree + descriptors -> "
+                      f"LightGlue vs the previous frame; {best['seconds']} s on {cores} threads, then "
+                      f"{runs['one_thread']['frames']} frames in {runs['one_thread']['seconds']} s on 1 thread",
+            "one_thread": runs["one_thread"], "all_cores": runs["all_cores"]}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4),
+                    help="BASELINE config: 4 (default) = full front-end, frames sharded over the GPUs; 2 = SuperPoint extract, ONE "
+                         "frame per call; 3 = SuperPoint x 2 + one LightGlue pair per call (a stereo frame).  2 and 3 are the "
+                         "batch-1 operating points of a live tracker: a step is one call, the line reports calls' latency")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames-per-gpu", type=int, default=FRAMES_PER_GPU,
                     help="frames per GPU per step (default 8 = BASELINE config #4's 64 frames / 8 GPUs)")
@@ -88,14 +114,14 @@ def main():
                     help="hand the frames over as HOST buffers (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--sequences", type=int, default=1,
                     help="independent image sequences (cameras) processed concurrently per GPU, one host thread each; "
-                         "steps are dealt round-robin to them.  2 gives ~+7 % frames/s by filling host-sync gaps, but the "
+                         "steps are dealt round-robin to them.  2 gives a few % more frames/s by filling host-sync gaps, but the "
                          "per-kernel HIP-event durations behind `roofline` then include time shared with the other "
                          "sequence's kernels, so the default keeps one sequence for clean attribution")
     ap.add_argument("--lg-gemm", choices=("f32", "bf16x3", "bf16x3_all"), default="f32",
                     help="arithmetic of LightGlue's linear layers for the TIMED region (dani_lg_set_gemm): f32 = f32 MFMA in the "
                          "oracle's canonical order (default, the headline); bf16x3 = three-term bf16 operand split, f32-accurate. "
-                         "A default run also reports the bf16x3 mode in `lg_gemm_bf16x3`, measured after the timed region")
-    ap.add_argument("--no-side-modes", action="store_true", help="skip the extra lg_gemm_bf16x3 measurement (profiling runs)")
+                         "A default run also reports the bf16x3 modes, measured after the timed region")
+    ap.add_argument("--no-side-modes", action="store_true", help="skip the extra bf16x3 / batch-1 measurements (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -122,43 +148,53 @@ def main():
             dist.init_process_group(backend)
 
     from dani_slam_amd import sharding
-    B = args.frames_per_gpu
-    shard = sharding.shard_frames(B * world, rank, world)   # this rank's block of the synthetic frames
-    frames = np.stack([synth.frame(i) for i in shard])
-    frames_bgr = np.stack([synth.frame_bgr(i) for i in shard])
+    cfg = args.config
+    B = {2: 1, 3: 2}.get(cfg, args.frames_per_gpu)
+    shard = sharding.shard_frames(B * world, rank, world)   # this rank's block of consecutive frames of the trajectory
+    frames, frames_bgr = synth.bench_frames(shard)
     d_frames = torch.from_numpy(frames).to(dev)          # inputs resident in HBM before the timed region
     d_bgr = torch.from_numpy(frames_bgr).to(dev)
-    weights = dict(synth.superpoint_weights(0)); weights.update(synth.lightglue_weights(0)); weights.update(synth.yolo_weights(0))
-    eng = frontend.Engine(device=local_rank, max_batch=B, max_width=W, max_height=H, weights=weights)
+    weights = synth.bench_weights()
+    eng = frontend.Engine(device=local_rank, max_batch=max(B, 2), max_width=W, max_height=H, weights=weights)
     eng.yolo_set_classes(synth.COCO_NAMES, synth.DYNAMIC_NAMES)   # coco.names is not shipped by the reference
     if args.lg_gemm != "f32":
         eng.lg_set_gemm(eng.LG_GEMM_BF16X3 if args.lg_gemm == "bf16x3" else eng.LG_GEMM_BF16X3_ALL)
 
     import threading
-    NSEQ = max(1, args.sequences)
+    NSEQ = max(1, args.sequences) if cfg == 4 else 1
     PROF_EVERY = 10
 
-    def step(seq=0):
+    def call(mode, seq=0, nb=None):
+        """mode 4: full front-end; 2: SuperPoint extract only; 3: SuperPoint x 2 + LightGlue of the (left, right) pair."""
+        nb = nb or B
+        kw = dict(nfeatures=NFEATURES, want_desc=True, copy=False, sequence=seq)
+        if mode == 2:
+            kw.update(use_yolo=False, match_previous=False)
+        elif mode == 3:
+            kw.update(use_yolo=False, stereo_pairs=True)
         if args.host_inputs:
-            return eng.frontend_batch(frames, frames_bgr, nfeatures=NFEATURES, want_desc=True, copy=False, sequence=seq)
-        return eng.frontend_batch(None, None, nfeatures=NFEATURES, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()),
-                                  shape=(B, H, W), want_desc=True, copy=False, sequence=seq)
+            return eng.frontend_batch(frames[:nb], frames_bgr[:nb] if mode == 4 else None, **kw)
+        return eng.frontend_batch(None, None, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()), shape=(nb, H, W), **kw)
 
-    def run_steps(total, collect):
-        """`total` steps dealt round-robin to NSEQ concurrent sequences (one host thread each)."""
+    def run_steps(total, collect, mode=cfg, nb=None):
+        """`total` steps dealt round-robin to NSEQ concurrent sequences (one host thread each).  Returns the last outputs,
+        the per-kernel profile averages over the sampled steps and every step's wall time in ms."""
         outs = [None] * NSEQ
         acc = [(np.zeros(12), np.zeros(4), np.zeros(3), np.zeros(3)) for _ in range(NSEQ)]
         errs = []
         nsamp = [0] * NSEQ
+        step_ms = [[] for _ in range(NSEQ)]
 
         def worker(seq):
             try:
                 for it in range(total // NSEQ + (1 if seq < total % NSEQ else 0)):
                     # per-kernel HIP-event timing costs ~0.4 ms per step (166 events): sample every PROF_EVERY-th step
-                    sample = collect and it % PROF_EVERY == 0
+                    sample = collect and mode == 4 and it % PROF_EVERY == 0
                     if collect:
                         eng.set_profiling(sample)
-                    outs[seq] = step(seq)
+                    ts = time.perf_counter()
+                    outs[seq] = call(mode, seq, nb)
+                    step_ms[seq].append((time.perf_counter() - ts) * 1e3)
                     if sample:
                         nsamp[seq] += 1
                         acc[seq][0][:] += eng.layer_timings()
@@ -167,13 +203,17 @@ def main():
                         acc[seq][3][:] += np.array(eng.lg_linear_profile(), np.float64)
             except Exception as ex:   # surface worker failures in the main thread
                 errs.append(ex)
-        th = [threading.Thread(target=worker, args=(q,)) for q in range(NSEQ)]
-        for t_ in th: t_.start()
-        for t_ in th: t_.join()
+        if NSEQ == 1:
+            worker(0)
+        else:
+            th = [threading.Thread(target=worker, args=(q,)) for q in range(NSEQ)]
+            for t_ in th: t_.start()
+            for t_ in th: t_.join()
         if errs:
             raise errs[0]
         ns = max(sum(nsamp), 1)   # per-step averages over the sampled steps
-        return outs, sum(a[0] for a in acc) / ns, sum(a[1] for a in acc) / ns, sum(a[2] for a in acc) / ns, sum(a[3] for a in acc) / ns
+        return (outs, sum(a[0] for a in acc) / ns, sum(a[1] for a in acc) / ns, sum(a[2] for a in acc) / ns,
+                sum(a[3] for a in acc) / ns, [x for s_ in step_ms for x in s_])
 
     def barrier():
         if world > 1:
@@ -192,102 +232,135 @@ def main():
     gc.disable()
     barrier()
     t0 = time.perf_counter()
-    outs, layer_ms, fe_ms, attn, lin = run_steps(args.steps, True)
+    outs, layer_ms, fe_ms, attn, lin, step_ms = run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     eng.set_profiling(False)
     out = next(o for o in outs if o is not None)
+    nk = [len(o["kpts"]) for o in out]
+    nmatch = [len(o["matches"]) for o in out]
+    nbox = [len(o["boxes"]) for o in out]
 
-    # outside the timed region: the same workload with LightGlue's matrix products in the other arithmetics
+    # ---- outside the timed region (N = 1): the opt-in arithmetics and the batch-1 operating points
     side = {}
     SIDE_STEPS = 100
-    if args.lg_gemm == "f32" and world == 1 and NSEQ == 1 and not args.no_side_modes:
-        ref = [(np.array(o["matches"]).copy(), np.array(o["scores"]).copy()) for o in step()]   # f32 mode
+    extras = cfg == 4 and args.lg_gemm == "f32" and world == 1 and NSEQ == 1 and not args.no_side_modes
+    if extras:
+        ref = [(np.array(o["matches"]).copy(), np.array(o["scores"]).copy()) for o in call(4)]   # f32 mode
         for key, mode, what in (("lg_gemm_bf16x3", eng.LG_GEMM_BF16X3, "linear layers"),
                                 ("lg_gemm_bf16x3_all", eng.LG_GEMM_BF16X3_ALL, "linear layers and attention contractions")):
             eng.lg_set_gemm(mode)
             run_steps(20, False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            outs3, _, fe3, attn3, lin3 = run_steps(SIDE_STEPS, True)
+            outs3, _, fe3, attn3, lin3, sm3 = run_steps(SIDE_STEPS, True)
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t1
             eng.set_profiling(False)
-            worst, flips = 0.0, 0
+            worst, flips, nm = 0.0, 0, 0
             for (m_a, s_a), o in zip(ref, outs3[0]):
                 a = {tuple(x): float(v) for x, v in zip(m_a.tolist(), s_a)}
                 b = {tuple(x): float(v) for x, v in zip(np.array(o["matches"]).tolist(), np.array(o["scores"]))}
-                flips += len(set(a) ^ set(b))
+                flips += len(set(a) ^ set(b)); nm += len(a)
                 worst = max([worst] + [abs(a[k] - b[k]) for k in set(a) & set(b)])
             side[key] = {"value": round(B * SIDE_STEPS / dt3, 3), "unit": "frames/s", "steps": SIDE_STEPS, "ms_per_step": round(dt3 / SIDE_STEPS * 1e3, 4),
-                         "lightglue_ms_per_step": round(float(fe3[2]), 3),
+                         "ms_per_step_median": pct(sm3, 50), "lightglue_ms_per_step": round(float(fe3[2]), 3),
                          "linear_avg_launch_ms": round(float(lin3[0]) / max(int(round(lin3[2])), 1), 4),
                          "attention_avg_launch_ms": round(float(attn3[0]) / max(int(round(attn3[2])), 1), 4),
-                         "max_abs_score_diff_vs_f32_mode": worst, "matches_not_in_both": flips,
+                         "matches_compared": nm, "max_abs_score_diff_vs_f32_mode": worst, "matches_not_in_both": flips,
                          "note": f"dani_lg_set_gemm({key[8:].upper()}): {what} as six bf16 MFMAs over three-term operand splits, "
                                  "f32 accumulation; opt-in, not the headline"}
         eng.lg_set_gemm(eng.LG_GEMM_F32)
+        # BASELINE configs #2 and #3: one call at a time, as a live tracker issues them (src/Frame.cc:420-427, :813-860)
+        lat = {}
+        for key, mode, nb, what in (("config2_superpoint_extract_1_frame", 2, 1, "SPextractor::operator() on one 640x480 frame, 1024 keypoints"),
+                                    ("config3_stereo_pair_sp_x2_plus_lightglue", 3, 2, "two extractions + one LightGlue pair (Frame::ComputeStereoMatches)")):
+            eng.frontend_reset()
+            run_steps(30, False, mode, nb)
+            torch.cuda.synchronize()
+            _, _, _, _, _, sm = run_steps(200, False, mode, nb)
+            lat[key] = {"median": pct(sm, 50), "p10": pct(sm, 10), "p90": pct(sm, 90), "calls": len(sm), "frames_per_call": nb,
+                        "frames_per_s": round(nb * len(sm) / (sum(sm) * 1e-3), 2), "what": what}
+        side["latency_b1_ms"] = lat
+        eng.frontend_reset()
     gc.enable()
 
     dt_max = sharding.reduce_max_seconds(dt, reduce_dev)
-    nk = [len(o["kpts"]) for o in out]
 
     if rank == 0:
         total_frames = B * world * args.steps
         fps = total_frames / dt_max
-        conv_dom_ms = float(sum(layer_ms[i] for i in DOMINANT_LAYERS))
-        conv_dom_flops = sum(exact_layer_flops(i, B) for i in DOMINANT_LAYERS)
-        conv_achieved = conv_dom_flops / (conv_dom_ms * 1e-3) / 1e12 if conv_dom_ms > 0 else 0.0
-        # second kernel by total time: LightGlue attention (18 launches per step)
-        attn_ms, attn_flop, attn_launches = float(attn[0]), float(attn[1]), int(round(attn[2]))
-        attn_achieved = attn_flop / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
-        # dominant kernel of the full front-end by total time (profiles/: linear_fm_kernel<64>, 55 launches per step)
-        lin_ms, lin_flop, lin_launches = float(lin[0]), float(lin[1]), int(round(lin[2]))
-        achieved = lin_flop / (lin_ms * 1e-3) / 1e12 if lin_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (committed)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        conv_ms = float(layer_ms.sum())
-        nmatch = [len(o["matches"]) for o in out]
-        nbox = [len(o["boxes"]) for o in out]
         res = {
             "metric": "frames/sec SuperPoint+LightGlue+YOLO front-end, 640x480, 1/2/4/8 MI355X",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.lg_gemm == "f32" else f"f32 (LightGlue matrix products: {args.lg_gemm} operand split on the bf16 MFMA, f32 accumulate)", "data": "synthetic" + (" (frames handed over as HOST buffers: PCIe-inclusive)" if args.host_inputs else ""),
-            "config": {"workload": "full front-end (BASELINE config #4 sharded): YOLOv5s boxes -> SuperPoint extract -> "
-                                   f"LightGlue vs previous frame, {B} synthetic 640x480 frames per GPU per step resident "
-                                   "in HBM, nFeatures=1024, nLevels=1, iniTh=0.015, minTh=0.007, LightGlue 9 layers "
-                                   "no early exit, seeded synthetic weights",
-                       "frames_per_gpu_per_step": B, "keypoints_per_frame": nk[:4], "matches_per_frame": nmatch[:4],
-                       "dynamic_boxes_per_frame": nbox[:4],
-                       "concurrent_sequences_per_gpu": NSEQ,
-                       "parallelism": f"frame-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "linear_fm_kernel<64> (LightGlue feature-major linear layers: 6 per layer x 9 + final_proj)",
-                         "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "launches_per_step": lin_launches,
-                         "avg_launch_ms": round(lin_ms / max(lin_launches, 1), 4),
-                         "algorithmic_gflop_per_step": round(lin_flop / 1e9, 2),
-                         "other_kernels": {
-                             "attn_kernel<4> (LightGlue f32 flash attention, 9 self + 9 cross launches; attn_ks_kernel below 512 workgroups)": {
-                                 "achieved": round(attn_achieved, 3), "frac": round(attn_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-                                 "avg_launch_ms": round(attn_ms / max(attn_launches, 1), 4), "launches_per_step": attn_launches,
-                                 "algorithmic_gflop_per_step": round(attn_flop / 1e9, 2)},
-                             DOMINANT_KERNEL: {"achieved": round(conv_achieved, 3),
-                                               "frac": round(conv_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-                                               "avg_launch_ms": round(conv_dom_ms / len(DOMINANT_LAYERS), 4),
-                                               "launches_per_step": len(DOMINANT_LAYERS)}}},
-            "stages_ms_per_step": {"yolo": round(float(fe_ms[0]), 3), "superpoint": round(float(fe_ms[1]), 3),
-                                   "lightglue": round(float(fe_ms[2]), 3), "total": round(float(fe_ms[3]), 3),
-                                   "sp_conv_stack_device": round(conv_ms, 3)},
-            "sp_conv_stack_tflops": round(SP_GFLOP_PER_FRAME * B / conv_ms, 2) if conv_ms > 0 else None,
-            "layer_ms": [round(float(x), 4) for x in layer_ms],
+            "step_ms": {"median": pct(step_ms, 50), "p10": pct(step_ms, 10), "p90": pct(step_ms, 90), "min": pct(step_ms, 0), "max": pct(step_ms, 100),
+                        "n": len(step_ms), "what": "wall time of every dani_frontend_batch call of the timed region on rank 0 (all sequences)"},
         }
+        if cfg == 4:
+            conv_dom_ms = float(sum(layer_ms[i] for i in DOMINANT_LAYERS))
+            conv_dom_flops = sum(exact_layer_flops(i, B) for i in DOMINANT_LAYERS)
+            conv_achieved = conv_dom_flops / (conv_dom_ms * 1e-3) / 1e12 if conv_dom_ms > 0 else 0.0
+            # second kernel by total time: LightGlue attention (18 launches per step)
+            attn_ms, attn_flop, attn_launches = float(attn[0]), float(attn[1]), int(round(attn[2]))
+            attn_achieved = attn_flop / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+            # dominant kernel of the full front-end by total time (profiles/: linear_fm_kernel<64>, 55 launches per step)
+            lin_ms, lin_flop, lin_launches = float(lin[0]), float(lin[1]), int(round(lin[2]))
+            achieved = lin_flop / (lin_ms * 1e-3) / 1e12 if lin_ms > 0 else 0.0
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (committed)
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profiles.sh), NOT measured in this run"
+                except Exception:
+                    traffic = None
+            conv_ms = float(layer_ms.sum())
+            res["config"] = {"workload": "full front-end (BASELINE config #4 sharded): YOLOv5s boxes -> SuperPoint extract -> "
+                                         f"LightGlue vs previous frame, {B} consecutive frames of a synthetic camera trajectory (2 deg + 8 px "
+                                         "per frame, 640x480) per GPU per step resident in HBM, nFeatures=1024, nLevels=1, iniTh=0.015, "
+                                         "minTh=0.007, LightGlue 9 layers no early exit, seeded synthetic weights (centred descriptor head)",
+                             "frames_per_gpu_per_step": B, "keypoints_per_frame": nk[:8], "matches_per_frame": nmatch[:8],
+                             "dynamic_boxes_per_frame": nbox[:8], "concurrent_sequences_per_gpu": NSEQ,
+                             "note_matches": "frame 0 of a step is matched against frame B-1 of the previous step (the same 8 frames "
+                                             "are replayed every step): a 14-degree jump, few matches; frames 1..B-1 are consecutive",
+                             "parallelism": f"frame-sharded x{world}, no data-path collective"}
+            res["roofline"] = {"bound": "mfma", "kernel": "linear_fm_kernel<64> (LightGlue feature-major linear layers: 6 per layer x 9 + final_proj)",
+                               "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                               "launches_per_step": lin_launches,
+                               "avg_launch_ms": round(lin_ms / max(lin_launches, 1), 4),
+                               "algorithmic_gflop_per_step": round(lin_flop / 1e9, 2),
+                               "other_kernels": {
+                                   "attn_kernel<4> (LightGlue f32 flash attention, 9 self + 9 cross launches; attn_ks_kernel below 512 workgroups)": {
+                                       "achieved": round(attn_achieved, 3), "frac": round(attn_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                       "avg_launch_ms": round(attn_ms / max(attn_launches, 1), 4), "launches_per_step": attn_launches,
+                                       "algorithmic_gflop_per_step": round(attn_flop / 1e9, 2)},
+                                   DOMINANT_KERNEL: {"achieved": round(conv_achieved, 3),
+                                                     "frac": round(conv_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
+                                                     "avg_launch_ms": round(conv_dom_ms / len(DOMINANT_LAYERS), 4),
+                                                     "launches_per_step": len(DOMINANT_LAYERS)}}}
+            # host wall-clock phases of one call (they overlap device work of the neighbouring phases; NOT device time per network)
+            res["stages_ms_per_step"] = {
+                "phase1_enqueue_sp_network_then_wait_for_yolo_boxes": round(float(fe_ms[0]), 3),
+                "phase2_sp_candidates_sync_quadtree_descriptors_enqueue": round(float(fe_ms[1]), 3),
+                "phase3_lightglue_enqueue_and_final_sync": round(float(fe_ms[2]), 3),
+                "call_total": round(float(fe_ms[3]), 3),
+                "sp_conv_stack_device_ms_sum_of_12_layers": round(conv_ms, 3)}
+            res["sp_conv_stack_tflops"] = round(SP_GFLOP_PER_FRAME * B / conv_ms, 2) if conv_ms > 0 else None
+            res["layer_ms"] = [round(float(x), 4) for x in layer_ms]
+        else:
+            what = {2: "BASELINE config #2: SuperPoint extract, ONE 640x480 frame per call, 1024 keypoints (SPextractor::operator(), src/Frame.cc:420-427)",
+                    3: "BASELINE config #3: SuperPoint x 2 + one LightGlue pair per call, 640x480, 1024 keypoints per frame "
+                       "(Frame::Frame's two ExtractORB calls + ComputeStereoMatches, src/Frame.cc:124-143, 813-860)"}[cfg]
+            res["config"] = {"workload": what + "; frames of the synthetic camera trajectory resident in HBM, seeded synthetic weights",
+                             "frames_per_call": B, "keypoints_per_frame": nk, "matches_per_frame": nmatch,
+                             "parallelism": f"replicas x{world}: every rank runs its own calls, no collective"}
+            res["latency_ms_per_call"] = res["step_ms"]
+            res["roofline"] = {"bound": "latency", "note": "one frame (pair) per call: the chain of dependent launches is launch / "
+                               "dependency-latency bound, not MFMA- or HBM-bound; the per-kernel roofline figures are those of the default run"}
         res.update(side)
         try:   # the facts the peaks in `roofline` are priced against (print them next to every roofline number)
             pr = torch.cuda.get_device_properties(dev)
@@ -297,8 +370,9 @@ def main():
                              "fp32_matrix_peak_tflops_used": FP32_MATRIX_PEAK_TFLOPS}
         except Exception:
             pass
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(frames[:4], frames_bgr[:4], weights)
+        if world == 1 and not args.no_cpu_baseline and cfg == 4:
+            n = min(len(frames), 8)
+            res["cpu_baseline"] = cpu_baseline(frames[:n], frames_bgr[:n], weights)
         print(json.dumps(res), flush=True)
     eng.close()
     if world > 1:

@@ -83,6 +83,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   if (B < 1 || B > e->cfg.max_batch) return fail(e, DANI_ERR_INVALID, "batch %d outside [1, %d]", B, e->cfg.max_batch);
   if (p->use_yolo && (!bgr || !dyn_boxes || !n_boxes || box_cap < 1)) return fail(e, DANI_ERR_INVALID, "use_yolo needs bgr + box outputs");
   if (p->match_previous && (!matches || !scores || !k_out || match_cap < 1)) return fail(e, DANI_ERR_INVALID, "match_previous needs match outputs");
+  if (p->match_previous && p->pair_mode != 0 && (p->pair_mode != 1 || (B & 1))) return fail(e, DANI_ERR_INVALID, "pair_mode 1 (stereo) needs an even number of frames; got pair_mode %d, B %d", p->pair_mode, B);
   SeqState* S0 = seq_state(e, 0);
   SeqState* S = seq_state(e, sequence);
   std::lock_guard<std::mutex> seq_lock(S->mu);
@@ -187,7 +188,8 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
       if (n_out[b]) memcpy(desc + (size_t)b * cap * 256, c->h_desc + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024);
     });
   };
-  if (p->match_previous) {
+  const bool stereo = p->match_previous && p->pair_mode == 1;
+  if (p->match_previous && !stereo) {
     std::vector<int32_t> n0(B), n1(B);
     for (int b = 0; b < B; b++) { n0[b] = b ? n_out[b - 1] : c->prev_n; n1[b] = n_out[b]; }
     const float sz[2] = {(float)W, (float)H};
@@ -198,6 +200,23 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kimg_all, c->d_desc_all, n0.data(), c->d_kimg, c->d_descout, n1.data(), sz, sz,
                              p->lg_threshold, matches, scores, match_cap, k_out);
     if (rc) { move_desc(); (void)hipStreamSynchronize(c->stream); return rc; }
+  } else if (stereo) {
+    // left = frame 2k, right = frame 2k+1: the slabs of one pair lie two frame slots apart, so LightGlue's per-pair stride
+    // (in_cap) is two slabs, and its per-pair output stride two match slots, starting at the right frame's slot
+    const int P = B / 2;
+    std::vector<int32_t> n0(P), n1(P), kk(P, 0);
+    for (int k = 0; k < P; k++) { n0[k] = n_out[2 * k]; n1[k] = n_out[2 * k + 1]; }
+    const float sz[2] = {(float)W, (float)H};
+    LgCall lg_call;
+    lg_call.ctx = c; lg_call.overlap = &move_desc;
+    rc = lg_match_impl(e, lg_call, P, 2 * c->kcap, 1, c->d_kimg, c->d_descout, n0.data(), c->d_kimg + (size_t)c->kcap * 2,
+                       c->d_descout + (size_t)c->kcap * 256, n1.data(), sz, sz, p->lg_threshold, matches + (size_t)match_cap * 2,
+                       scores + match_cap, 2 * match_cap, kk.data());
+    if (rc) { move_desc(); (void)hipStreamSynchronize(c->stream); return rc; }
+    for (int k = 0; k < P; k++) {
+      k_out[2 * k] = 0; k_out[2 * k + 1] = kk[k];
+      if (kk[k] > match_cap) { move_desc(); (void)hipStreamSynchronize(c->stream); return fail(e, DANI_ERR_CAPACITY, "pair %d: %d matches (> %d)", k, kk[k], match_cap); }
+    }
   }
   const bool synced = cache_enqueued;   // LightGlue ran: its final synchronise covered the cache copies
   move_desc();
@@ -205,7 +224,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   HIP_TRY(e, hipStreamSynchronize(c->stream2));
   HIP_TRY(e, hipGetLastError());
   if (e->profiling) sp_read_timers(c, true);
-  c->prev_n = n_out[B - 1];
+  c->prev_n = stereo ? 0 : n_out[B - 1];
   S->ms[2] = ms_since(t2);
   S->ms[3] = ms_since(t0);
   return DANI_OK;

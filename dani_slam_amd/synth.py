@@ -24,12 +24,17 @@ SP_LAYERS = [
 ]
 
 
-def superpoint_weights(seed: int = 0, pb_gain: float = 3.0, dustbin_bias: float = 9.5) -> dict:
+def superpoint_weights(seed: int = 0, pb_gain: float = 3.0, dustbin_bias: float = 9.5, centered_desc: bool = False) -> dict:
     """He-uniform weights (variance preserving through the ReLU stack) + small biases.
 
     `pb_gain` / `dustbin_bias` shape the detector head so that the 65-way softmax is peaky enough for
     roughly 1-3 k pixels of a synthetic 640x480 frame to exceed the reference's iniTh=0.015
     (Examples/RGB-D/TUM3.yaml:42-55); with an untrained flat head every pixel would sit at 1/65=0.0154.
+
+    `centered_desc` subtracts from convDb.bias the per-channel mean of the raw descriptor head output over synthetic
+    frames 0..3 (a stored calibration constant, tools/make_desc_center.py): random weights give every descriptor the
+    same large offset, so that different keypoints have cosine 0.85 and LightGlue matches almost nothing between two
+    views of one scene; centred, it finds hundreds (bench.py's moving-camera sequence).  Keypoints are unaffected.
     """
     rng = np.random.RandomState(seed)
     w = {}
@@ -40,6 +45,12 @@ def superpoint_weights(seed: int = 0, pb_gain: float = 3.0, dustbin_bias: float 
         w[name + ".bias"] = rng.uniform(-0.05, 0.05, size=(cout,)).astype(np.float32)
     w["convPb.weight"] = (w["convPb.weight"] * np.float32(pb_gain)).astype(np.float32)
     w["convPb.bias"][64] += np.float32(dustbin_bias)
+    if centered_desc:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"sp_desc_center_seed{seed}.npy")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: run tools/make_desc_center.py (only seed 0 is shipped)")
+        w["convDb.bias"] = (w["convDb.bias"] - np.load(path)).astype(np.float32)
     return w
 
 
@@ -81,6 +92,47 @@ def frame_bgr(i: int, width: int = 640, height: int = 480) -> np.ndarray:
     g = frame(i, width, height).astype(np.float64)
     gains = (0.9, 1.0, 0.8)
     return np.stack([np.clip(np.rint(g * s), 0, 255) for s in gains], axis=-1).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Moving-camera sequence ("frame i vs the same frame warped by a fixed affine, 2 degree rotation,
+# 8-px shift"): frame i is a 640x480 window of one large synthetic canvas, rotated by 2 degrees per frame and moved
+# 8 px per frame along a circle, bilinearly resampled.  Consecutive frames are therefore related by exactly that warp,
+# whatever i is, and a shard of consecutive frames is a piece of one camera trajectory.
+# ---------------------------------------------------------------------------------------------------------
+_CANVAS = {}
+SEQ_CANVAS = 1408     # the window's half diagonal (400) + the path's diameter (2 x 229) + margin, either side
+
+
+def _canvas(seed: int = 0) -> np.ndarray:
+    if seed not in _CANVAS:
+        _CANVAS[seed] = frame(10_000 + seed, SEQ_CANVAS, SEQ_CANVAS).astype(np.float64)
+    return _CANVAS[seed]
+
+
+def sequence_frame(i: int, width: int = 640, height: int = 480, rot_deg: float = 2.0, step_px: float = 8.0, seed: int = 0) -> np.ndarray:
+    """Frame i of the synthetic camera trajectory (uint8 [H, W])."""
+    base = _canvas(seed)
+    S = base.shape[0]
+    th = np.deg2rad(rot_deg) * i
+    R = step_px / np.deg2rad(rot_deg)            # consecutive window centres are step_px apart (arc length)
+    cx = S / 2.0 + R * np.sin(th); cy = S / 2.0 - R * np.cos(th)
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+    u = xs - (width - 1) / 2.0; v = ys - (height - 1) / 2.0
+    c, s = np.cos(th), np.sin(th)
+    X = cx + c * u - s * v; Y = cy + s * u + c * v
+    x0 = np.floor(X); y0 = np.floor(Y)
+    fx = X - x0; fy = Y - y0
+    x0 = np.clip(x0.astype(np.int64), 0, S - 2); y0 = np.clip(y0.astype(np.int64), 0, S - 2)
+    out = (base[y0, x0] * (1 - fx) * (1 - fy) + base[y0, x0 + 1] * fx * (1 - fy)
+           + base[y0 + 1, x0] * (1 - fx) * fy + base[y0 + 1, x0 + 1] * fx * fy)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def sequence_frame_bgr(i: int, width: int = 640, height: int = 480, **kw) -> np.ndarray:
+    """BGR variant of sequence_frame for the YOLO detector (same per-channel gains as frame_bgr)."""
+    g = sequence_frame(i, width, height, **kw).astype(np.float64)
+    return np.stack([np.clip(np.rint(g * s), 0, 255) for s in (0.9, 1.0, 0.8)], axis=-1).astype(np.uint8)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -249,3 +301,15 @@ def vocab_tree(seed, k=10, L=3, dim=256, stop_fraction=0.05):
     return dict(child_offsets=offs, child_ids=ids, desc=np.stack(desc), weight=weight, word_id=word_id, L=L)
 
 
+# ---------------------------------------------------------------- bench.py's workload (shared with tests/test_bench_shape_gpu.py)
+def bench_weights(seed: int = 0) -> dict:
+    """Weights of the bench workload: SuperPoint with the centred descriptor head (see superpoint_weights), LightGlue, YOLOv5s."""
+    w = dict(superpoint_weights(seed, centered_desc=True))
+    w.update(lightglue_weights(seed)); w.update(yolo_weights(seed))
+    return w
+
+
+def bench_frames(indices):
+    """(gray [n, 480, 640] u8, bgr [n, 480, 640, 3] u8) for frames `indices` of the moving-camera sequence."""
+    idx = list(indices)
+    return (np.stack([sequence_frame(i) for i in idx]), np.stack([sequence_frame_bgr(i) for i in idx]))

@@ -224,6 +224,12 @@ typedef struct dani_frontend_params {
   int32_t match_previous;  /* 1: LightGlue-match every frame against its predecessor in the sequence */
   float lg_threshold;      /* 0.05 (include/LightGlue.h:23) */
   int32_t lapping[2];      /* vLappingArea */
+  int32_t pair_mode;       /* with match_previous: 0 = sequence (frame b against frame b-1, frame 0 against the previous call's
+                              last frame); 1 = stereo: frames (2k, 2k+1) of the call are the left / right images of one
+                              timestamp and LightGlue matches left against right (Frame::Frame's two ExtractORB calls +
+                              Frame::ComputeStereoMatches, src/Frame.cc:124-143, :813-860); B must be even, nothing is
+                              cached across calls; matches / scores / k_out of pair k are delivered in the slots of frame
+                              2k+1 as (index in left, index in right), the slots of frame 2k report k_out = 0 */
 } dani_frontend_params;
 
 /* `sequence` selects one of any number of independent image sequences (cameras): each has its own stream, workspace

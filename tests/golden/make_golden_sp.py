@@ -17,7 +17,6 @@ import sys
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from dani_slam_amd import synth  # noqa: E402
@@ -26,48 +25,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(8)
 
 
-def forward(x, w):
-    """SuperPoint::forward, SuperPoint.cpp:56-99.  Returns (prob [H,W], desc [256,Hc,Wc], taps)."""
-    t = {k: torch.from_numpy(v) for k, v in w.items()}
-    taps = []
-
-    def conv(name, x, relu, pad):
-        y = F.conv2d(x, t[name + ".weight"], t[name + ".bias"], stride=1, padding=pad)
-        if relu:
-            y = torch.relu(y)
-        taps.append(y[0].numpy().copy())
-        return y
-
-    x = conv("conv1a", x, True, 1); x = conv("conv1b", x, True, 1); x = F.max_pool2d(x, 2, 2)
-    x = conv("conv2a", x, True, 1); x = conv("conv2b", x, True, 1); x = F.max_pool2d(x, 2, 2)
-    x = conv("conv3a", x, True, 1); x = conv("conv3b", x, True, 1); x = F.max_pool2d(x, 2, 2)
-    x = conv("conv4a", x, True, 1); x = conv("conv4b", x, True, 1)
-    cPa = conv("convPa", x, True, 1); semi = conv("convPb", cPa, False, 0)
-    cDa = conv("convDa", x, True, 1); desc = conv("convDb", cDa, False, 0)
-    dn = torch.norm(desc, 2, 1)
-    desc = desc.div(torch.unsqueeze(dn, 1))
-    semi = torch.softmax(semi, 1)
-    semi = semi[:, 0:64]
-    semi = semi.permute(0, 2, 3, 1)
-    Hc, Wc = semi.size(1), semi.size(2)
-    semi = semi.contiguous().view(-1, Hc, Wc, 8, 8)
-    semi = semi.permute(0, 1, 3, 2, 4)
-    semi = semi.contiguous().view(-1, Hc * 8, Wc * 8)
-    return semi[0].numpy(), desc[0].numpy(), taps
-
-
-def compute_descriptors(desc_map, kxy, PH, PW):
-    """SPDetector::computeDescriptors, SuperPoint.cpp:246-274 (kxy = n x (x, y))."""
-    mDesc = torch.from_numpy(desc_map)[None]
-    fk = torch.from_numpy(kxy)
-    grid = torch.zeros(1, 1, fk.size(0), 2)
-    grid[0, 0, :, 0] = 2.0 * fk[:, 0] / PW - 1
-    grid[0, 0, :, 1] = 2.0 * fk[:, 1] / PH - 1
-    d = F.grid_sample(mDesc, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
-    d = d.squeeze(0).squeeze(1)
-    dn = torch.norm(d, 2, 1)
-    d = d.div(torch.unsqueeze(dn, 1))
-    return d.transpose(0, 1).contiguous().numpy()
+from oracle.aten_ref import sp_compute_descriptors as compute_descriptors  # noqa: E402  (the ATen op sequence lives in
+from oracle.aten_ref import sp_forward as forward  # noqa: E402                      oracle/aten_ref.py, shared with bench.py)
 
 
 def main():

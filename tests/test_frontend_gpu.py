@@ -90,21 +90,40 @@ def test_capacity_errors_are_reported(weights):
     e.close()
 
 
-def test_fused_call_with_a_pyramid(weights, sp_weights):
+def _assert_matches_like_oracle(w, prev, ref, got, min_matches):
+    mo, so = lg.match_descriptors(w, prev["kpts"], prev["desc"], ref["kpts"], ref["desc"], (640, 480), (640, 480), 0.05)
+    a = {tuple(x): float(v) for x, v in zip(mo.tolist(), so)}
+    b = {tuple(x): float(v) for x, v in zip(got["matches"].tolist(), got["scores"])}
+    assert len(a) >= min_matches, len(a)                                        # not a vacuous comparison
+    assert len(set(a) ^ set(b)) <= max(2, len(a) // 50), (len(a), len(b), len(set(a) ^ set(b)))
+    assert max(abs(a[k] - b[k]) for k in set(a) & set(b)) < 1e-3
+
+
+@pytest.mark.parametrize("lapping", [(0, 0), (0, 1000)])
+def test_fused_call_with_a_pyramid(sp_weights, lapping):
     """nLevels > 1 through the fused call: the dynamic-box cull stays in the kernel (with its scale drift replay, quirk
-    Q6) instead of moving to the host as it does for single-level calls."""
+    Q6) instead of moving to the host as it does for single-level calls, and LightGlue must see what the reference hands
+    to matchDescriptors -- mvKeys, i.e. keypoint->pt SCALED by the level's factor and in the mono / stereo partition
+    order of operator() (src/SPextractor.cpp:164-216), next to the un-permuted descriptor rows (:159).  With lapping =
+    {0, 1000} (the monocular setting, src/Frame.cc:313) every keypoint goes to the back in reverse order."""
     from dani_slam_amd import frontend
-    e = frontend.Engine(device=0, max_batch=2, weights=weights)
+    w = synth.bench_weights()                      # centred descriptor head: two views of one scene match by the hundred
+    e = frontend.Engine(device=0, max_batch=2, weights=w)
     e.yolo_set_classes(yo.COCO_NAMES, yo.DYNAMIC_NAMES)
-    gray = np.stack([synth.frame(1), synth.frame(4)]); bgr = np.stack([synth.frame_bgr(1), synth.frame_bgr(4)])
-    out = e.frontend_batch(gray, bgr, nfeatures=600, nlevels=3, scaleFactor=1.2)
+    gray, bgr = synth.bench_frames([0, 1])
+    gray[1, 200:330, 100:240] = synth.frame(1)[200:330, 100:240]; bgr[1] = synth.frame_bgr(1)      # frame 1 gets real dynamic boxes
+    out = e.frontend_batch(gray, bgr, nfeatures=600, nlevels=3, scaleFactor=1.2, lapping=lapping)
+    refs = []
     for i in range(2):
-        ok, dets, dyn, dmap = yo.detect(weights, bgr[i])
-        assert [tuple(int(v) for v in r) for r in out[i]["boxes"]] == [tuple(r) for r in dyn] and len(dyn) >= 1
-        ref = oracle.sp_extract(gray[i], sp_weights, nfeatures=600, nlevels=3, scaleFactor=1.2, boxes=dyn)
+        ok, dets, dyn, dmap = yo.detect(w, bgr[i])
+        assert [tuple(int(v) for v in r) for r in out[i]["boxes"]] == [tuple(r) for r in dyn]
+        ref = oracle.sp_extract(gray[i], w, nfeatures=600, nlevels=3, scaleFactor=1.2, boxes=dyn, lapping=lapping)
         assert np.array_equal(out[i]["kpts"], ref["kpts"])
         assert np.array_equal(out[i]["desc"], ref["desc"])
-    assert len(out[1]["matches"]) >= 0
+        assert out[i]["mono_index"] == ref["mono_index"]
+        refs.append(ref)
+    assert len(yo.detect(w, bgr[1])[2]) >= 1 and (refs[0]["octave"] > 0).sum() > 100
+    _assert_matches_like_oracle(w, refs[0], refs[1], out[1], 30)
     e.close()
 
 
@@ -123,4 +142,26 @@ def test_sequences_keep_their_own_predecessor(weights):
         assert len(r["matches"]) > 100 and np.all(r["matches"][:, 0] == r["matches"][:, 1])
     c = e.frontend_batch(*f(3), nfeatures=NF, sequence=0)[0]            # frame 3 against sequence 0's frame 0: not identity
     assert not (len(c["matches"]) > 100 and np.all(c["matches"][:, 0] == c["matches"][:, 1]))
+    e.close()
+
+
+def test_stereo_pair_mode(sp_weights):
+    """pair_mode = 1: frames (2k, 2k+1) are the left / right images of one timestamp -- two extractions and ONE
+    LightGlue match per pair (Frame::Frame's two ExtractORB calls + ComputeStereoMatches, src/Frame.cc:124-143, 813-860),
+    nothing carried from call to call; BASELINE config #3 is one such pair."""
+    from dani_slam_amd import frontend
+    w = synth.bench_weights()
+    e = frontend.Engine(device=0, max_batch=4, weights=w)
+    gray, _ = synth.bench_frames([0, 1, 5, 6])
+    refs = [oracle.sp_extract(g, w, nfeatures=NF) for g in gray]
+    for B in (2, 4):
+        for rep in range(2):      # the second call must not see anything of the first
+            out = e.frontend_batch(gray[:B], None, nfeatures=NF, use_yolo=False, stereo_pairs=True)
+            for b in range(B):
+                assert np.array_equal(out[b]["kpts"], refs[b]["kpts"]) and np.array_equal(out[b]["desc"], refs[b]["desc"])
+            for k in range(B // 2):
+                assert len(out[2 * k]["matches"]) == 0
+                _assert_matches_like_oracle(w, refs[2 * k], refs[2 * k + 1], out[2 * k + 1], 20)
+    with pytest.raises(frontend.DaniError):
+        e.frontend_batch(gray[:3], None, nfeatures=NF, use_yolo=False, stereo_pairs=True)      # odd number of frames
     e.close()

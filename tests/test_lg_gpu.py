@@ -159,6 +159,17 @@ def test_large_batch_kernel_with_ragged_sets(lg_weights, sp_weights):
         m, s = e.lg_match(k0, d0, k1, d1, SIZE, SIZE, 0.05)
         assert np.array_equal(res3[p][0], m), p
         np.testing.assert_allclose(res3[p][1], s, rtol=0, atol=1e-4)
+    # ... and both 128-query kernels DIRECTLY against the oracle (not only against the other HIP kernel): four pairs of
+    # the batched results, every ragged size class, f32 (attn_kernel<4>) and bf16x3 (attn_x3w_kernel)
+    for p in (0, 1, 2, 3):
+        k0, d0, k1, d1, _ = pairs[p]
+        mo, so = lg.match_descriptors(lg_weights, k0, d0, k1, d1, SIZE, SIZE, 0.05)
+        want = {tuple(x): float(v) for x, v in zip(mo.tolist(), so)}
+        assert len(want) > 300
+        for tag, r in (("f32", res), ("bf16x3_all", res3)):
+            got = {tuple(x): float(v) for x, v in zip(r[p][0].tolist(), r[p][1])}
+            assert len(set(got) ^ set(want)) <= max(2, len(want) // 100), (tag, p, len(got), len(want))
+            assert max(abs(got[k] - want[k]) for k in set(got) & set(want)) < 1e-3, (tag, p)      # the stated bar
     e.close()
 
 

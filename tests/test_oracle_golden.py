@@ -52,3 +52,48 @@ def test_g2_full_frame(sp_weights, golden_dir):
     np.testing.assert_allclose(d, g["descriptors"], rtol=0, atol=1e-5)
     # Q7: columns (channels) have unit norm over the keypoints, rows do not
     np.testing.assert_allclose(np.linalg.norm(d.astype(np.float64), axis=0), 1.0, atol=1e-5)
+
+
+def test_g1b_crop_all_layers(sp_weights, golden_dir):
+    """G1 on a 96 x 128 crop (the size the HIP engine accepts; tests/test_aten_fixtures_gpu.py runs it on the GPU)."""
+    g = np.load(os.path.join(golden_dir, "sp_g1b_crop.npz"))
+    prob, desc, taps = oracle.superpoint_forward(g["img"], sp_weights, want_taps=True)
+    for i, tp in enumerate(taps):
+        assert tuple(g[f"tap{i}_shape"]) == tp.shape
+        np.testing.assert_allclose(tp.reshape(-1)[::53], g[f"tap{i}_sample"], rtol=2e-4, atol=2e-5, err_msg=f"layer {i}")
+    np.testing.assert_allclose(prob, g["prob"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(desc, g["desc"], rtol=0, atol=1e-5)
+
+
+def g10_compare(g, i, prob, kpts, desc=None):
+    """Frame i of G10 against a prob map / keypoint list / descriptors of another f32 implementation.  Returns
+    (threshold flips, keypoints not in both sets, same keypoint order).  Every flipped pixel must lie within the
+    fixture's margin (1e-4) of its threshold in ATen's map -- anything else is an arithmetic error, not rounding."""
+    flips = 0
+    for tag, th in (("015", 0.015), ("007", 0.007)):
+        a = np.unpackbits(g[f"f{i}_mask{tag}"])[:prob.size].astype(bool).reshape(prob.shape)
+        idx = np.nonzero((a != (prob > np.float32(th))).reshape(-1))[0]
+        near = set(g[f"f{i}_near{tag}_idx"].tolist())
+        assert all(int(f) in near for f in idx), f"frame {i}: a pixel far from {th} changed side"
+        flips += len(idx)
+    ka = {tuple(x) for x in g[f"f{i}_kpts"].tolist()}; kb = {tuple(x) for x in kpts.tolist()}
+    same = kpts.shape == g[f"f{i}_kpts"].shape and np.array_equal(kpts, g[f"f{i}_kpts"])
+    if desc is not None and f"f{i}_desc_rows4" in g.files and same:
+        np.testing.assert_allclose(desc[::4], g[f"f{i}_desc_rows4"], rtol=0, atol=1e-5)
+    return flips, len(ka ^ kb), same
+
+
+def test_g10_sixteen_frames_threshold_flips_and_keypoints(sp_weights, golden_dir):
+    """SURVEY section 7 'hard parts': the count of threshold-margin flips against LibTorch-CPU over many frames and the
+    keypoint-set differences they cause.  G10 holds ATen's decisions for synthetic frames 0..15 and the keypoints the
+    reference's host logic selects from ATen's prob map.  Measured: 0 flips in 2 x 16 x 307 200 decisions, identical
+    keypoints in identical order on all 16 frames (the bound below allows rounding-level flips should torch change)."""
+    g = np.load(os.path.join(golden_dir, "sp_g10_frames.npz"))
+    flips = kdiff = 0
+    for i in range(int(g["nframes"])):
+        r = oracle.sp_extract(synth.frame(i), sp_weights, want_maps=True)
+        f, k, same = g10_compare(g, i, r["prob"], r["kpts"], r["desc"])
+        flips += f; kdiff += k
+        assert abs(len(r["kpts"]) - len(g[f"f{i}_kpts"])) <= 2
+    print(f"G10: {flips} threshold flips, {kdiff} keypoints not in both sets over 16 frames")
+    assert flips <= 16 and kdiff <= 32

@@ -30,3 +30,27 @@ def test_yolo_oracle_vs_aten(golden_dir):
         got = taps[f"raw{lvl}"][sl]
         assert got.shape == ref.shape
         np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3)
+
+
+def test_lightglue_oracle_vs_aten_three_sizes(golden_dir):
+    """G7 at N = M in {7, 128, 1024}: final descriptors, best log-score per row and both arg-max
+    directions against the ATen restatement (tests/golden/make_golden_lg_sizes.py)."""
+    g = np.load(os.path.join(golden_dir, "lg_g7_sizes.npz"))
+    w = synth.lightglue_weights(0)
+    for n in g["sizes"].tolist():
+        k0, d0, k1, d1, _ = synth.matching_pair(100 + n, n0=n, n1=n)
+        k0n, k1n = lg_oracle.normalize_keypoints(k0, (640, 480)), lg_oracle.normalize_keypoints(k1, (640, 480))
+        m, s, ex = lg_oracle.forward(w, k0n, k1n, d0, d1, want_intermediates=True)
+        st = 1 if n < 64 else 8
+        np.testing.assert_allclose(ex["d0"][::st], g[f"n{n}_x0"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(ex["d1"][::st], g[f"n{n}_x1"], rtol=0, atol=5e-5)
+        sc = ex["scores"]
+        tol = 2e-3 * max(1.0, float(np.abs(g[f"n{n}_rowmax"]).max()) / 50.0)
+        np.testing.assert_allclose(sc.max(1), g[f"n{n}_rowmax"], rtol=0, atol=tol)
+        np.testing.assert_allclose(sc[::st, ::st], g[f"n{n}_scores"], rtol=2e-5, atol=tol)
+        # arg-max may differ only where ATen's own top-2 margin is inside the tolerance
+        for got, ref, axis in ((sc.argmax(1), g[f"n{n}_rowarg"], 1), (sc.argmax(0), g[f"n{n}_colarg"], 0)):
+            for i in np.nonzero(got != ref)[0]:
+                line = sc[i] if axis == 1 else sc[:, i]
+                top = np.sort(line)[::-1]
+                assert top[0] - top[1] < 2 * tol, (n, axis, int(i))
