@@ -58,6 +58,27 @@ def pct(xs, q):
     return round(float(np.percentile(np.asarray(xs, np.float64), q)), 4) if len(xs) else None
 
 
+def host_cpu_share():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a job a share
+    of the host's cores; 256 threads on a 16-core quota are throttled to a crawl)."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(gray, bgr, weights):
     """The reference's CPU path restated: LibTorch's own ATen-CPU kernels for SuperPoint::forward, the LightGlue and
     YOLOv5s forwards (the reference runs all three on LibTorch-CPU: src/SPextractor.cpp:230, src/LightGlue.cpp:10,
@@ -67,12 +88,25 @@ def cpu_baseline(gray, bgr, weights):
     import torch
     from oracle import aten_ref, oracle
     oracle.lib()
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cpu_share()
+    os.environ["OMP_NUM_THREADS"] = str(cores)      # the C host logic of the oracle (OpenMP) gets the same share
     tw = aten_ref.torch_weights(weights)
     runs = {}
-    for label, nthreads, budget_s, max_frames in (("all_cores", cores, 12.0, 48), ("one_thread", 1, 12.0, 8)):
-        torch.set_num_threads(nthreads)
+    # "all cores": ATen's intra-op pool does not always scale to the whole share on these layer sizes (and a share reported
+    # too large is throttled), so the thread count is picked by a one-frame trial among {share, 64, 16}, and stated
+    trial = {}
+    for nt in sorted({cores, min(cores, 64), min(cores, 16)}):      # ascending; stop as soon as more threads are slower
+        torch.set_num_threads(nt)
         aten_ref.frontend_frame(tw, gray[0], bgr[0], None, nfeatures=NFEATURES)      # untimed: first-call set-up of the ATen kernels
+        t0 = time.perf_counter()
+        aten_ref.frontend_frame(tw, gray[0], bgr[0], None, nfeatures=NFEATURES)
+        trial[nt] = time.perf_counter() - t0
+        if trial[nt] > min(trial.values()):
+            break
+    many = min(trial, key=trial.get)
+    for label, nthreads, budget_s, max_frames in (("all_cores", many, 12.0, 48), ("one_thread", 1, 12.0, 8)):
+        torch.set_num_threads(nthreads)
+        aten_ref.frontend_frame(tw, gray[0], bgr[0], None, nfeatures=NFEATURES)
         stages, prev, n = {}, None, 0
         t0 = time.perf_counter()
         while True:
@@ -85,15 +119,16 @@ def cpu_baseline(gray, bgr, weights):
         runs[label] = {"frames_per_s": round(n / dt, 4), "threads": nthreads, "frames": n, "seconds": round(dt, 2),
                        "matches_last_pair": int(len(prev.get("matches", []))),
                        "stage_ms_per_frame": {k: round(v / n * 1e3, 2) for k, v in stages.items()}}
+    runs["all_cores"]["thread_count_trial_s_per_frame"] = {str(k): round(v, 3) for k, v in trial.items()}
     torch.set_num_threads(cores)
     best = runs["all_cores"]
-    return {"value": best["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
-            "flavour": f"ATen-CPU op sequence of the reference (torch {torch.__version__}, torch.get_num_threads() = {cores}) + "
+    return {"value": best["frames_per_s"], "unit": "frames/s", "cores": best["threads"], "kind": "port", "host_cpu_share": cores,
+            "flavour": f"ATen-CPU op sequence of the reference (torch {torch.__version__}, torch.get_num_threads() = {best['threads']}) + "
                        "restated host logic in C (the reference's own 204-cell loop indexes tensors element by element and is "
                        "slower than this); the reference's sources need OpenCV and cannot be built on this box",
             "sample": f"{best['frames']} consecutive 640x480 frames of the bench sequence, one at a time (batch 1, as the "
                       f"reference): YOLOv5s + NMS + box logic -> SuperPoint forward + 204-cell loop + quadtree + descriptors -> "
-                      f"LightGlue vs the previous frame; {best['seconds']} s on {cores} threads, then "
+                      f"LightGlue vs the previous frame; {best['seconds']} s on {best['threads']} threads, then "
                       f"{runs['one_thread']['frames']} frames in {runs['one_thread']['seconds']} s on 1 thread",
             "one_thread": runs["one_thread"], "all_cores": runs["all_cores"]}
 
