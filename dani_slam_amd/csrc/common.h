@@ -91,8 +91,8 @@ inline ConvVariant conv_small_variant(ConvVariant v) {
 void launch_conv1a(const uint8_t* img, int B, int H, int W, int stride, size_t img_frame_stride, const float* w /*64*9*/,
                    const float* bias /*64*/, const ActDesc& out, hipStream_t s);
 // false = shape outside the kernel's 32-bit addressing contract: nothing was launched (DANI_ERR_UNSUPPORTED upstream)
-bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s);
-bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s);
+bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s, int reserve_lds = 0);
+bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds = 0);
 const char* conv_kernel_name(ConvVariant v);
 
 // semi [B][65(+pad)][..] padded planar -> prob [B][PH][PW] dense

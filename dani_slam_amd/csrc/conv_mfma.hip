@@ -235,7 +235,7 @@ using CfgRow32nSilu      = Cfg<3, 1, 1, 32, 2, 8, ACT_SILU, false, 1>;
 using CfgConv1Row32nSilu = Cfg<1, 1, 1, 32, 2, 32, ACT_SILU, false, 1>;
 
 template <class C>
-static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
+static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds) {
   ConvArgs a;
   a.in = io.in; a.w = L.w_packed; a.bias = L.bias_packed; a.out = io.out; a.res = io.res;
   a.Cin = L.CinPad; a.Cout = L.Cout; a.H = io.H; a.W = io.W;
@@ -248,43 +248,46 @@ static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   // 32-bit byte offsets inside a frame (epilogue): refused, not launched; the engine reports DANI_ERR_UNSUPPORTED
   if ((size_t)(L.cout_tiles * C::NCO + 8) * io.oHp * io.oWp >= ((size_t)1 << 30)) return false;
   const int grid = B * a.tiles_x * a.tiles_y * a.cout_tiles;
-  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), 0, s, a);
+  // reserve_lds: dynamic LDS the kernel never touches.  It only lowers how many of THESE workgroups fit on a CU, so that
+  // a slot (registers, waves and the rest of the LDS) stays free for the workgroups of a concurrent stream (the fused
+  // front-end: YOLO's chain of small dependent kernels next to SuperPoint's huge ones, sp_engine.cpp).
+  hipLaunchKernelGGL(conv_mfma_kernel<C>, dim3(grid), dim3(256), (size_t)reserve_lds, s, a);
   return true;
 }
 
-bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s) {
+bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds) {
   switch (L.variant) {
-    case CONV3_ROW32_RELU: return launch_cfg<CfgRow32Relu>(L, io, B, s);
-    case CONV3_ROW32_RELU_POOL: return launch_cfg<CfgRow32ReluPool>(L, io, B, s);
-    case CONV3_BLK16_RELU: return launch_cfg<CfgBlk16Relu>(L, io, B, s);
-    case CONV1_BLK16_LINEAR: return launch_cfg<CfgConv1Blk16>(L, io, B, s);
-    case CONV6S2_ROW32_SILU: return launch_cfg<CfgStem6Row32>(L, io, B, s);
-    case CONV3S2_ROW32_SILU: return launch_cfg<CfgS2Row32Silu>(L, io, B, s);
-    case CONV3S2_BLK16_SILU: return launch_cfg<CfgS2Blk16Silu>(L, io, B, s);
-    case CONV3_ROW32_SILU: return launch_cfg<CfgRow32Silu>(L, io, B, s);
-    case CONV3_BLK16_SILU: return launch_cfg<CfgBlk16Silu>(L, io, B, s);
-    case CONV1_ROW32_SILU: return launch_cfg<CfgConv1Row32Silu>(L, io, B, s);
-    case CONV1_BLK16_SILU: return launch_cfg<CfgConv1Blk16Silu>(L, io, B, s);
-    case CONV3_BLK16S_RELU: return launch_cfg<CfgBlk16sRelu>(L, io, B, s);
-    case CONV1_BLK16S_LINEAR: return launch_cfg<CfgConv1Blk16s>(L, io, B, s);
-    case CONV3_BLK16S_SILU: return launch_cfg<CfgBlk16sSilu>(L, io, B, s);
-    case CONV3S2_BLK16S_SILU: return launch_cfg<CfgS2Blk16sSilu>(L, io, B, s);
-    case CONV1_BLK16S_SILU: return launch_cfg<CfgConv1Blk16sSilu>(L, io, B, s);
-    case CONV6S2_ROW32N_SILU: return launch_cfg<CfgStem6Row32n>(L, io, B, s);
-    case CONV3_ROW32N_SILU: return launch_cfg<CfgRow32nSilu>(L, io, B, s);
-    case CONV1_ROW32N_SILU: return launch_cfg<CfgConv1Row32nSilu>(L, io, B, s);
+    case CONV3_ROW32_RELU: return launch_cfg<CfgRow32Relu>(L, io, B, s, reserve_lds);
+    case CONV3_ROW32_RELU_POOL: return launch_cfg<CfgRow32ReluPool>(L, io, B, s, reserve_lds);
+    case CONV3_BLK16_RELU: return launch_cfg<CfgBlk16Relu>(L, io, B, s, reserve_lds);
+    case CONV1_BLK16_LINEAR: return launch_cfg<CfgConv1Blk16>(L, io, B, s, reserve_lds);
+    case CONV6S2_ROW32_SILU: return launch_cfg<CfgStem6Row32>(L, io, B, s, reserve_lds);
+    case CONV3S2_ROW32_SILU: return launch_cfg<CfgS2Row32Silu>(L, io, B, s, reserve_lds);
+    case CONV3S2_BLK16_SILU: return launch_cfg<CfgS2Blk16Silu>(L, io, B, s, reserve_lds);
+    case CONV3_ROW32_SILU: return launch_cfg<CfgRow32Silu>(L, io, B, s, reserve_lds);
+    case CONV3_BLK16_SILU: return launch_cfg<CfgBlk16Silu>(L, io, B, s, reserve_lds);
+    case CONV1_ROW32_SILU: return launch_cfg<CfgConv1Row32Silu>(L, io, B, s, reserve_lds);
+    case CONV1_BLK16_SILU: return launch_cfg<CfgConv1Blk16Silu>(L, io, B, s, reserve_lds);
+    case CONV3_BLK16S_RELU: return launch_cfg<CfgBlk16sRelu>(L, io, B, s, reserve_lds);
+    case CONV1_BLK16S_LINEAR: return launch_cfg<CfgConv1Blk16s>(L, io, B, s, reserve_lds);
+    case CONV3_BLK16S_SILU: return launch_cfg<CfgBlk16sSilu>(L, io, B, s, reserve_lds);
+    case CONV3S2_BLK16S_SILU: return launch_cfg<CfgS2Blk16sSilu>(L, io, B, s, reserve_lds);
+    case CONV1_BLK16S_SILU: return launch_cfg<CfgConv1Blk16sSilu>(L, io, B, s, reserve_lds);
+    case CONV6S2_ROW32N_SILU: return launch_cfg<CfgStem6Row32n>(L, io, B, s, reserve_lds);
+    case CONV3_ROW32N_SILU: return launch_cfg<CfgRow32nSilu>(L, io, B, s, reserve_lds);
+    case CONV1_ROW32N_SILU: return launch_cfg<CfgConv1Row32nSilu>(L, io, B, s, reserve_lds);
   }
   return false;
 }
 
 // SuperPoint convenience form: whole tensors in the standard padded planar layout
-bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s) {
+bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s, int reserve_lds) {
   ConvIO io;
   io.in = in.p; io.out = out.p; io.res = nullptr;
   io.H = in.H; io.W = in.W;   // stride-1 layers: conv output dims == input dims (pooling happens in the epilogue)
   io.iHp = in.Hp; io.iWp = in.Wp; io.ipady = in.pady; io.oHp = out.Hp; io.oWp = out.Wp; io.opady = out.pady;
   io.in_fs = in.frame_stride(); io.out_fs = out.frame_stride(); io.res_fs = 0;
-  return launch_conv_io(L, io, B, s);
+  return launch_conv_io(L, io, B, s, reserve_lds);
 }
 
 const char* conv_kernel_name(ConvVariant v) {

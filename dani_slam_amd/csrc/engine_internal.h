@@ -73,6 +73,8 @@ struct Context {
   // pinned host staging
   float* h_kxy = nullptr;  // [B][kcap][2] followed by per-level (offset, count) ints [nlevels][2][B]
   bool cands_enqueued = false;   // phase 1 already ran cell NMS + candidate read-back (SpCall::host_cull)
+  bool spec_valid = false;       // phase 3 ran: spec_sels[b] = quadtree selection of frame b computed WITHOUT the boxes
+  std::vector<std::vector<int>> spec_sels;
   float* h_desc = nullptr; // [B][kcap][256]: descriptor read-back of the fused call (copied out under LightGlue)
   int32_t* h_boxes = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -222,9 +224,13 @@ Context* last_ctx(dani_engine* e);   // the calling thread's last context, if it
 // How the fused front-end (dani_frontend_batch) drives the three stages; the public ABI entry points pass the defaults.
 struct SpCall {
   Context* ctx = nullptr;             // run on this context (the sequence's own) instead of acquiring a free one
-  int phase = 0;                      // 0: whole extractor; 1: enqueue the network only; 2: everything after it
+  int phase = 0;                      // 0: whole extractor; 1: enqueue the network only; 2: everything after it;
+                                      // 3 (between 1 and 2, host_cull calls): fetch the candidates and run the quadtrees
+                                      // speculatively without boxes, while the YOLO chain is still running
   bool keep_desc_on_device = false;   // `desc` may be null: descriptors are consumed on the device (LightGlue)
   bool defer_desc_sync = false;       // descriptor read-back into pinned staging on stream2, no final synchronise
+  int reserve_lds_bytes = 0;          // fused call with YOLO on the second stream: unused dynamic LDS added to the conv layers in
+  unsigned reserve_lds_mask = 0;      // reserve_lds_mask (bit i = layer i), so that a CU keeps a free slot for YOLO's workgroups
   bool host_cull = false;             // single-level calls: candidate NMS + read-back are enqueued in phase 1, without the
                                       // boxes; the dynamic-box cull (exact and idempotent at scale 1) runs on the host in phase 2
 };
@@ -232,6 +238,7 @@ struct YoloCall {
   Context* ctx = nullptr;
   bool alt_stream = false;            // run on the context's second (high-priority) stream, next to the SuperPoint network
   std::function<void(int, const float*, int)>* post = nullptr;   // per frame, inside the NMS worker: (frame, dets6, n)
+  std::function<void()>* before_sync = nullptr;   // host work of the caller to run after the chain is enqueued, before waiting for it
 };
 struct LgCall {
   Context* ctx = nullptr;

@@ -119,6 +119,11 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   SpCall sp_call;
   sp_call.ctx = c; sp_call.keep_desc_on_device = true; sp_call.phase = 1;
   sp_call.host_cull = p->use_yolo && p->sp.nlevels == 1;
+  if (p->use_yolo) {   // tuning knobs of the slot reservation (defaults below are the measured optimum)
+    static const int pad_kb = getenv("DANI_SP_LDS_PAD_KB") ? atoi(getenv("DANI_SP_LDS_PAD_KB")) : 0;
+    static const unsigned pad_mask = getenv("DANI_SP_LDS_PAD_MASK") ? (unsigned)strtoul(getenv("DANI_SP_LDS_PAD_MASK"), nullptr, 0) : 0u;
+    sp_call.reserve_lds_bytes = pad_kb * 1024; sp_call.reserve_lds_mask = pad_mask;
+  }
   int rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
                            octave.data(), size.data(), desc, cap, n_out, mono_index);
   if (rc) return rc;
@@ -143,6 +148,14 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
       kk[b] = yolo_dynamic_areas(d6, n, W, H, cn.data(), (int)cn.size(), dn.data(), (int)dn.size(), nullptr, tmp.data() + (size_t)b * tstride, dcap + 1);
     };
     yolo_call.post = &areas;
+    // while the YOLO chain is still running: fetch SuperPoint's candidates and run the quadtrees without boxes (sp phase 3)
+    std::function<void()> speculate = [&] {
+      if (!sp_call.host_cull) return;
+      SpCall sc = sp_call; sc.phase = 3;
+      (void)sp_extract_impl(e, sc, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
+                            octave.data(), size.data(), desc, cap, n_out, mono_index);
+    };
+    yolo_call.before_sync = &speculate;
     rc = yolo_detect_impl(e, yolo_call, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
     if (rc) return rc;
     for (int b = 0; b < B; b++) {

@@ -342,12 +342,26 @@ constexpr int AT_STRIDE = 33;
 // (head, set), one per tail query; the linear workgroup id (dispatch order) is re-read so that ALL main tiles come
 // first -- their count fills the chip's slots in whole rounds -- and the short tail-query workgroups run last, on the
 // CUs that finish first.  Returns the tail query index, or -1 for a main tile (bx = its query tile).
+//
+// XCD locality: workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own 4 MiB L2.  In plain grid
+// order the gx query tiles of one (head, set) -- which all read that pair's K and V, 512 KiB at 1024 keys -- land on 8
+// different XCDs, so every L2 fetches every K/V: 305 MB of HBM/fabric traffic per launch against 67 MB algorithmic at
+// 16 x 1025 keypoints (profiles/r01_pmc_summary.json).  The remap below gives all query tiles of a (head, set) group to
+// ONE XCD, in consecutive dispatch slots (so they are resident together and share the tiles in that L2): with
+// L = 8 * slot + xcd, group = 8 * (slot / gx) + xcd and tile = slot % gx.  Groups beyond the last multiple of 8 keep the
+// plain order.  Speed only: any placement computes the same values.
 __device__ __forceinline__ int attn_role(int tail_slots, int& bx, int& by, int& bz) {
   bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
-  if (!tail_slots) return -1;
   const int gx = gridDim.x - tail_slots, gy = gridDim.y;
-  const int L = blockIdx.x + gridDim.x * (blockIdx.y + gy * blockIdx.z), nmain = gx * gy * gridDim.z;
-  if (L < nmain) { bx = L % gx; by = (L / gx) % gy; bz = L / (gx * gy); return -1; }
+  const int L = blockIdx.x + gridDim.x * (blockIdx.y + gy * blockIdx.z), ngroups = gy * gridDim.z, nmain = gx * ngroups;
+  if (L < nmain) {
+    const int full = (ngroups & ~7) * gx;      // ids covered by whole octets of groups
+    int g, t;
+    if (L < full) { const int slot = L >> 3; g = ((slot / gx) << 3) + (L & 7); t = slot % gx; }
+    else { const int r = L - full; g = (ngroups & ~7) + r / gx; t = r % gx; }
+    bx = t; by = g % gy; bz = g / gy;
+    return -1;
+  }
   const int t = L - nmain;
   bx = 0; by = (t / tail_slots) % gy; bz = t / (tail_slots * gy);
   return t % tail_slots;

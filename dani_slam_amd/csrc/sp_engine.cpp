@@ -245,8 +245,9 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     }
     return 0;
   };
-  if (phase != 2) {
+  if (phase != 2 && phase != 3) {
     c->cands_enqueued = false;
+    c->spec_valid = false;
     // ---- inputs
     const uint8_t* dimg = imgs;
     const size_t fbytes = (size_t)H * stride;
@@ -274,7 +275,8 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       if (lprof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
       const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
       for (int i = 1; i < 12; i++) {
-        if (!launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, s)) {
+        const int reserve = (call.reserve_lds_mask >> i) & 1 ? call.reserve_lds_bytes : 0;
+        if (!launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, s, reserve)) {
           (void)hipStreamSynchronize(s);
           return fail(e, DANI_ERR_UNSUPPORTED, "%s at %dx%d: activation tensor exceeds the conv kernel's 32-bit addressing range", kSp[i].name, L.W, L.H);
         }
@@ -293,6 +295,47 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       return DANI_OK;
     }
   }
+  const int minBorderX = 19 - 3, minBorderY = minBorderX;
+  // wait for the candidate read-back; frames with more than CAND_FAST candidates get their remainder in a second copy
+  auto fetch_candidates = [&]() -> int {
+    host_pool().prewake();   // the quadtree tasks start as soon as this synchronise returns
+    HIP_TRY(e, hipStreamSynchronize(s));
+    bool more = false;
+    for (int l = 0; l < NL; l++) {
+      Context::Level& L = c->lv[l];
+      for (int b = 0; b < B; b++) {
+        int nc = L.cells.empty() ? 0 : L.h_cand_count[b];
+        if (nc > CAND_CAP) return fail(e, DANI_ERR_CAPACITY, "frame %d level %d has %d candidates (> %d)", b, l, nc, CAND_CAP);
+        L.h_cand_count[b] = nc;
+        if (nc > CAND_FAST) {
+          more = true;
+          HIP_TRY(e, hipMemcpyAsync(L.h_cand + ((size_t)b * CAND_CAP + CAND_FAST) * 3, L.cand + ((size_t)b * CAND_CAP + CAND_FAST) * 3, (size_t)(nc - CAND_FAST) * 12, hipMemcpyDeviceToHost, s));
+        }
+      }
+    }
+    if (more) HIP_TRY(e, hipStreamSynchronize(s));
+    return 0;
+  };
+  if (phase == 3) {
+    // Speculation (fused single-level call): the candidates are on the host before YOLO's chain has finished, and the
+    // host is idle until it has.  The dynamic-box cull (src/SPextractor.cpp:314-352) only REMOVES candidates, so for a frame
+    // whose boxes turn out to contain none of its candidates -- every frame without a dynamic object -- the quadtree
+    // over the un-culled list is the final one.  Phase 2 checks that per frame and redoes the others.
+    c->spec_valid = false;
+    if (!c->cands_enqueued || NL != 1) return DANI_OK;
+    if ((rc = fetch_candidates())) return rc;
+    if ((int)c->spec_sels.size() < B) c->spec_sels.resize(B);
+    std::vector<char> okf(B, 1);
+    host_pool().run(B, [&](int b) {
+      const Context::Level& L = c->lv[0];
+      const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+      okf[b] = distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[0], c->spec_sels[b]);
+    });
+    bool all_ok = true;
+    for (int b = 0; b < B; b++) all_ok = all_ok && okf[b];
+    c->spec_valid = all_ok;
+    return DANI_OK;
+  }
   int nboxes_total = 0;
   if (boxes && box_offsets) nboxes_total = box_offsets[B];
   if (nboxes_total > c->box_cap) return fail(e, DANI_ERR_INVALID, "too many dynamic boxes (%d)", nboxes_total);
@@ -307,26 +350,12 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
   if (!c->cands_enqueued && (rc = enqueue_candidates(c->d_boxes, c->d_box_offsets))) return rc;
   HIP_TRY(e, hipEventRecord(c->ev[2], s));
   HIP_TRY(e, hipGetLastError());
-  host_pool().prewake();   // the quadtree tasks start as soon as this synchronise returns
-  HIP_TRY(e, hipStreamSynchronize(s));
-  bool more = false;
-  for (int l = 0; l < NL; l++) {
-    Context::Level& L = c->lv[l];
-    for (int b = 0; b < B; b++) {
-      int nc = L.cells.empty() ? 0 : L.h_cand_count[b];
-      if (nc > CAND_CAP) return fail(e, DANI_ERR_CAPACITY, "frame %d level %d has %d candidates (> %d)", b, l, nc, CAND_CAP);
-      L.h_cand_count[b] = nc;
-      if (nc > CAND_FAST) {
-        more = true;
-        HIP_TRY(e, hipMemcpyAsync(L.h_cand + ((size_t)b * CAND_CAP + CAND_FAST) * 3, L.cand + ((size_t)b * CAND_CAP + CAND_FAST) * 3, (size_t)(nc - CAND_FAST) * 12, hipMemcpyDeviceToHost, s));
-      }
-    }
-  }
-  if (more) HIP_TRY(e, hipStreamSynchronize(s));
+  const bool speculated = c->spec_valid && c->cands_enqueued && NL == 1;
+  c->spec_valid = false;
+  if (!speculated && (rc = fetch_candidates())) return rc;
 
   // ---- host: quadtree per (frame, level) + keypoint assembly (SPextractor.cpp:359-376, :164-216), frames in parallel
   const auto t0 = std::chrono::steady_clock::now();
-  const int minBorderX = 19 - 3, minBorderY = minBorderX;
   int32_t* h_lv = reinterpret_cast<int32_t*>(c->h_kxy + (size_t)MB * c->kcap * 2);   // [level][0: offset, 1: count][MB]
   std::vector<int> frame_status(B, DANI_OK);
   const bool host_cull = c->cands_enqueued;
@@ -336,6 +365,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     for (int l = 0; l < NL; l++) {
       const Context::Level& L = c->lv[l];
       HostKey* keys = reinterpret_cast<HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+      bool culled = false;
       if (host_cull && boxes && box_offsets && box_offsets[b + 1] > box_offsets[b]) {
         // dynamic-box cull of SPextractor.cpp:314-352 at scale 1: (p + border) tested with Rect::contains (left / top
         // inclusive, right / bottom exclusive, saturate_cast<int> = round half to even); the round trip is exact, so
@@ -350,8 +380,10 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
           }
           if (!inside) keys[m++] = keys[i];
         }
+        culled = m != L.h_cand_count[b];
         L.h_cand_count[b] = m;
       }
+      if (speculated && !culled) { sels[l].swap(c->spec_sels[b]); continue; }   // nothing was culled: the speculative quadtree stands
       if (!distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[l], sels[l]))
         frame_status[b] = DANI_ERR_UNSUPPORTED;   // cannot happen for levels ensure_shapes accepted and in-cell candidates
     }

@@ -343,6 +343,7 @@ int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, i
   HIP_TRY(e, hipMemcpyAsync(Y->h_count, Y->cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(e, hipMemcpy2DAsync(Y->h_cand, (size_t)YOLO_CAND_CAP * 32, Y->cand, (size_t)YOLO_CAND_CAP * 32, (size_t)YOLO_CAND_FAST * 32, B,
                               hipMemcpyDeviceToHost, s));
+  if (call.before_sync) (*call.before_sync)();   // the caller's host work that does not need the detections
   HIP_TRY(e, hipStreamSynchronize(s));
   bool more = false;
   for (int b = 0; b < B; b++) {
