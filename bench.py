@@ -156,6 +156,9 @@ def main():
                     help="arithmetic of LightGlue's linear layers for the TIMED region (dani_lg_set_gemm): f32 = f32 MFMA in the "
                          "oracle's canonical order (default, the headline); bf16x3 = three-term bf16 operand split, f32-accurate. "
                          "A default run also reports the bf16x3 modes, measured after the timed region")
+    ap.add_argument("--no-boundary-exchange", action="store_true",
+                    help="N > 1: treat every rank's frames as a sequence of its own instead of exchanging the shard-boundary frame "
+                         "(rank r's first frame is then matched against rank r's own last frame of the previous step)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra bf16x3 / batch-1 measurements (profiling runs)")
     args = ap.parse_args()
 
@@ -198,6 +201,12 @@ def main():
     import threading
     NSEQ = max(1, args.sequences) if cfg == 4 else 1
     PROF_EVERY = 10
+    # N > 1: the batch is ONE sequence of consecutive frames sharded over the ranks (BASELINE config #4), so the pair
+    # (last frame of rank r-1, first frame of rank r) crosses a GPU boundary: extract -> all-gather of every rank's last
+    # frame (features packed on the device, one RCCL all_gather_into_tensor over xGMI) -> LightGlue with that predecessor
+    boundary = cfg == 4 and world > 1 and NSEQ == 1 and not args.no_boundary_exchange
+    CAP = NFEATURES + 12
+    carry = {"slab": None}      # rank 0: the last rank's final frame of the previous step
 
     def call(mode, seq=0, nb=None):
         """mode 4: full front-end; 2: SuperPoint extract only; 3: SuperPoint x 2 + LightGlue of the (left, right) pair."""
@@ -207,9 +216,27 @@ def main():
             kw.update(use_yolo=False, match_previous=False)
         elif mode == 3:
             kw.update(use_yolo=False, stereo_pairs=True)
+        if mode == 4 and boundary:
+            kw.update(match_previous=False)
         if args.host_inputs:
-            return eng.frontend_batch(frames[:nb], frames_bgr[:nb] if mode == 4 else None, **kw)
-        return eng.frontend_batch(None, None, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()), shape=(nb, H, W), **kw)
+            out_ = eng.frontend_batch(frames[:nb], frames_bgr[:nb] if mode == 4 else None, **kw)
+        else:
+            out_ = eng.frontend_batch(None, None, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()), shape=(nb, H, W), **kw)
+        if mode == 4 and boundary:
+            slabs = sharding.exchange_boundary_features(eng, nb - 1, CAP, reduce_dev, seq)
+            pred = slabs[rank - 1] if rank > 0 else carry["slab"]
+            if pred is None:
+                eng.frontend_reset(seq)
+                res_ = eng.frontend_match_resident(nb, cap=CAP, sequence=seq)
+            elif pred.is_cuda:
+                res_ = eng.frontend_match_resident(nb, pred_device_ptr=pred.data_ptr(), pred_cap=CAP, cap=CAP, sequence=seq)
+            else:
+                res_ = eng.frontend_match_resident(nb, pred=pred.numpy(), cap=CAP, sequence=seq)
+            if rank == 0:
+                carry["slab"] = slabs[world - 1].clone()
+            for o_, (m_, s_) in zip(out_, res_):
+                o_["matches"], o_["scores"] = m_, s_
+        return out_
 
     def run_steps(total, collect, mode=cfg, nb=None):
         """`total` steps dealt round-robin to NSEQ concurrent sequences (one host thread each).  Returns the last outputs,
@@ -321,6 +348,12 @@ def main():
     gc.enable()
 
     dt_max = sharding.reduce_max_seconds(dt, reduce_dev)
+    first_pair = None
+    if world > 1 and cfg == 4:   # matches of every rank's FIRST frame (the pair that crosses the shard boundary), for the report
+        t_ = torch.tensor([nmatch[0]], dtype=torch.int64, device=reduce_dev or "cpu")
+        g_ = torch.empty(world, dtype=torch.int64, device=reduce_dev or "cpu")
+        dist.all_gather_into_tensor(g_, t_)
+        first_pair = [int(v) for v in g_.cpu().tolist()]
 
     if rank == 0:
         total_frames = B * world * args.steps
@@ -359,9 +392,12 @@ def main():
                                          "minTh=0.007, LightGlue 9 layers no early exit, seeded synthetic weights (centred descriptor head)",
                              "frames_per_gpu_per_step": B, "keypoints_per_frame": nk[:8], "matches_per_frame": nmatch[:8],
                              "dynamic_boxes_per_frame": nbox[:8], "concurrent_sequences_per_gpu": NSEQ,
+                             "first_frame_matches_per_rank": first_pair,
                              "note_matches": "frame 0 of a step is matched against frame B-1 of the previous step (the same 8 frames "
                                              "are replayed every step): a 14-degree jump, few matches; frames 1..B-1 are consecutive",
-                             "parallelism": f"frame-sharded x{world}, no data-path collective"}
+                             "parallelism": (f"frame-sharded x{world}; one all-gather of every rank's last-frame features per step (1 MB per rank, "
+                                             "device buffers) for the pair that crosses a shard boundary" if boundary else
+                                             f"frame-sharded x{world}, no data-path collective")}
             res["roofline"] = {"bound": "mfma", "kernel": "linear_fm_kernel<64> (LightGlue feature-major linear layers: 6 per layer x 9 + final_proj)",
                                "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,

@@ -20,6 +20,9 @@ struct SeqState {
   // per-call host scratch, kept between calls (a fresh 0.8 MB vector per call costs a memset on the critical path)
   std::vector<float> dets, size;
   std::vector<int32_t> octave, frame_boxes;
+  // resident features of the last dani_frontend_batch call (for dani_frontend_export_features / _match_resident)
+  int res_B = 0, res_W = 0, res_H = 0;
+  std::vector<int32_t> res_n;
 };
 // one SeqState (context + cached previous frame) per (engine, sequence id); id 0 also holds the class lists
 SeqState* seq_state(dani_engine* e, int id = 0) {
@@ -189,6 +192,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   auto enqueue_cache = [&] {   // the last frame's features become the next call's predecessor (slot 0 of the slabs)
     if (cache_enqueued) return;
     cache_enqueued = true;
+    if (!p->match_previous || (p->match_previous && p->pair_mode == 1)) return;   // extract-only / stereo calls cache nothing
     (void)hipMemcpyAsync(c->d_kimg_all, c->d_kimg + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream);
     (void)hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream);
   };
@@ -237,9 +241,71 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   HIP_TRY(e, hipStreamSynchronize(c->stream2));
   HIP_TRY(e, hipGetLastError());
   if (e->profiling) sp_read_timers(c, true);
-  c->prev_n = stereo ? 0 : n_out[B - 1];
+  if (p->match_previous) c->prev_n = stereo ? 0 : n_out[B - 1];   // an extract-only call leaves the predecessor to dani_frontend_match_resident
+  S->res_B = B; S->res_W = W; S->res_H = H; S->res_n.assign(n_out, n_out + B);
   S->ms[2] = ms_since(t2);
   S->ms[3] = ms_since(t0);
+  return DANI_OK;
+}
+
+int dani_frontend_export_features(dani_engine* e, int32_t sequence, int32_t frame, float* dst, int32_t dst_on_device, int32_t cap,
+                                  int32_t* n_out) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!dst || cap < 1) return fail(e, DANI_ERR_INVALID, "bad dani_frontend_export_features argument");
+  SeqState* S = seq_state(e, sequence);
+  std::lock_guard<std::mutex> seq_lock(S->mu);
+  Context* c = S->ctx;
+  if (!c || frame < 0 || frame >= S->res_B) return fail(e, DANI_ERR_INVALID, "sequence %d holds no resident frame %d", sequence, frame);
+  const int n = S->res_n[frame];
+  if (n > cap) { if (n_out) *n_out = n; return fail(e, DANI_ERR_CAPACITY, "frame has %d keypoints (> %d)", n, cap); }
+  HIP_TRY(e, hipSetDevice(e->device));
+  const hipMemcpyKind kind = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  const float cnt = (float)n;
+  HIP_TRY(e, hipMemcpyAsync(dst, &cnt, 4, dst_on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost, c->stream));
+  if (n) {
+    HIP_TRY(e, hipMemcpyAsync(dst + 1, c->d_kimg + (size_t)frame * c->kcap * 2, (size_t)n * 8, kind, c->stream));
+    HIP_TRY(e, hipMemcpyAsync(dst + 1 + (size_t)cap * 2, c->d_descout + (size_t)frame * c->kcap * 256, (size_t)n * 1024, kind, c->stream));
+  }
+  HIP_TRY(e, hipStreamSynchronize(c->stream));   // &cnt is a stack variable; the slab is ready for the collective on return
+  if (n_out) *n_out = n;
+  return DANI_OK;
+}
+
+int dani_frontend_match_resident(dani_engine* e, int32_t sequence, const float* pred, int32_t pred_on_device, int32_t pred_cap,
+                                 float lg_threshold, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!matches || !scores || !k_out || match_cap < 1 || (pred && pred_cap < 1)) return fail(e, DANI_ERR_INVALID, "bad dani_frontend_match_resident argument");
+  SeqState* S = seq_state(e, sequence);
+  std::lock_guard<std::mutex> seq_lock(S->mu);
+  Context* c = S->ctx;
+  const int B = S->res_B;
+  if (!c || B < 1) return fail(e, DANI_ERR_INVALID, "sequence %d holds no resident frames (call dani_frontend_batch first)", sequence);
+  HIP_TRY(e, hipSetDevice(e->device));
+  t_last_seq = S;
+  if (pred) {   // the neighbouring rank's last frame becomes slot 0 of the feature slabs
+    float cnt = 0.0f;
+    HIP_TRY(e, hipMemcpy(&cnt, pred, 4, pred_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+    const int pn = (int)cnt;
+    if (pn < 0 || pn > pred_cap || pn > c->kcap) return fail(e, DANI_ERR_INVALID, "predecessor slab holds %d keypoints (cap %d, engine %d)", pn, pred_cap, c->kcap);
+    const hipMemcpyKind kind = pred_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (pn) {
+      HIP_TRY(e, hipMemcpyAsync(c->d_kimg_all, pred + 1, (size_t)pn * 8, kind, c->stream));
+      HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, pred + 1 + (size_t)pred_cap * 2, (size_t)pn * 1024, kind, c->stream));
+    }
+    c->prev_n = pn;
+  }
+  std::vector<int32_t> n0(B), n1(B);
+  for (int b = 0; b < B; b++) { n0[b] = b ? S->res_n[b - 1] : c->prev_n; n1[b] = S->res_n[b]; }
+  const float sz[2] = {(float)S->res_W, (float)S->res_H};
+  LgCall lg_call;
+  lg_call.ctx = c;
+  int rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kimg_all, c->d_desc_all, n0.data(), c->d_kimg, c->d_descout, n1.data(), sz, sz,
+                         lg_threshold, matches, scores, match_cap, k_out);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(c->d_kimg_all, c->d_kimg + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(e, hipStreamSynchronize(c->stream));
+  c->prev_n = S->res_n[B - 1];
   return DANI_OK;
 }
 

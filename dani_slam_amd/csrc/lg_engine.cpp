@@ -483,6 +483,76 @@ int dani_lg_match(dani_engine* e, const float* kpts0, const float* desc0, int32_
                              scores, cap, k_out);
 }
 
+int dani_lg_match_groups(dani_engine* e, const float* kpts0, const float* desc0, int32_t n0, const float* kpts1,
+                         const float* desc1, int32_t n1, int32_t G, const int32_t* off0, const int32_t* idx0, const int32_t* off1,
+                         const int32_t* idx1, const float* size0, const float* size1, float threshold, int32_t* matches,
+                         float* scores, int32_t* match_offsets, int32_t cap) {
+  if (!e) return DANI_ERR_INVALID;
+  if (G < 0 || n0 < 0 || n1 < 0 || !match_offsets || (G && (!off0 || !off1)) || cap < 0 || (cap && (!matches || !scores)))
+    return fail(e, DANI_ERR_INVALID, "bad dani_lg_match_groups argument");
+  match_offsets[0] = 0;
+  if (G == 0) return DANI_OK;
+  if (off0[0] != 0 || off1[0] != 0) return fail(e, DANI_ERR_INVALID, "group offsets must start at 0");
+  int maxn = 1;
+  for (int g = 0; g < G; g++) {
+    const int a = off0[g + 1] - off0[g], b = off1[g + 1] - off1[g];
+    if (a < 0 || b < 0) return fail(e, DANI_ERR_INVALID, "group %d: offsets not monotone", g);
+    maxn = std::max(maxn, std::max(a, b));
+  }
+  const int t0 = off0[G], t1 = off1[G];
+  if ((t0 && (!idx0 || !kpts0 || !desc0)) || (t1 && (!idx1 || !kpts1 || !desc1))) return fail(e, DANI_ERR_INVALID, "null feature arrays");
+  for (int i = 0; i < t0; i++) if (idx0[i] < 0 || idx0[i] >= n0) return fail(e, DANI_ERR_INVALID, "idx0[%d] = %d outside [0, %d)", i, idx0[i], n0);
+  for (int i = 0; i < t1; i++) if (idx1[i] < 0 || idx1[i] >= n1) return fail(e, DANI_ERR_INVALID, "idx1[%d] = %d outside [0, %d)", i, idx1[i], n1);
+  // Only groups with two non-empty sides reach LightGlue (the reference's `if (!kpsKF1.empty() && ... )`, :970); they become
+  // the pairs of ONE batched forward pass: every set is padded to 32 tokens, all pairs share each of the ~170 launches.
+  std::vector<int> live;
+  for (int g = 0; g < G; g++) if (off0[g + 1] > off0[g] && off1[g + 1] > off1[g]) live.push_back(g);
+  const int P = (int)live.size();
+  std::vector<int32_t> kk(std::max(P, 1), 0);
+  std::vector<int32_t> m; std::vector<float> sc;
+  if (P) {
+    try {
+      // gather: what the reference does row by row with cv::Mat::push_back, into the slab layout of dani_lg_match_batch
+      std::vector<float> K0((size_t)P * maxn * 2), K1((size_t)P * maxn * 2), D0((size_t)P * maxn * 256), D1((size_t)P * maxn * 256);
+      std::vector<int32_t> c0(P), c1(P);
+      host_pool().run(P, [&](int p) {
+        const int g = live[p];
+        c0[p] = off0[g + 1] - off0[g]; c1[p] = off1[g + 1] - off1[g];
+        for (int i = 0; i < c0[p]; i++) {
+          const int r = idx0[off0[g] + i];
+          memcpy(&K0[((size_t)p * maxn + i) * 2], kpts0 + (size_t)r * 2, 8);
+          memcpy(&D0[((size_t)p * maxn + i) * 256], desc0 + (size_t)r * 256, 1024);
+        }
+        for (int i = 0; i < c1[p]; i++) {
+          const int r = idx1[off1[g] + i];
+          memcpy(&K1[((size_t)p * maxn + i) * 2], kpts1 + (size_t)r * 2, 8);
+          memcpy(&D1[((size_t)p * maxn + i) * 256], desc1 + (size_t)r * 256, 1024);
+        }
+      });
+      m.resize((size_t)P * maxn * 2); sc.resize((size_t)P * maxn);
+      const int rc = lg_match_impl(e, LgCall{}, P, maxn, 0, K0.data(), D0.data(), c0.data(), K1.data(), D1.data(), c1.data(), size0, size1,
+                                   threshold, m.data(), sc.data(), maxn, kk.data());
+      if (rc) return rc;
+    } catch (const std::exception&) {
+      return fail(e, DANI_ERR_INVALID, "out of host memory for %d groups of up to %d keypoints", P, maxn);
+    }
+  }
+  int total = 0, p = 0;
+  for (int g = 0; g < G; g++) {
+    const bool is_live = p < P && live[p] == g;
+    const int k = is_live ? kk[p] : 0;
+    if (total + k <= cap && k) {
+      memcpy(matches + (size_t)total * 2, &m[(size_t)p * maxn * 2], (size_t)k * 8);
+      memcpy(scores + total, &sc[(size_t)p * maxn], (size_t)k * 4);
+    }
+    total += k;
+    match_offsets[g + 1] = total;
+    if (is_live) p++;
+  }
+  if (total > cap) return fail(e, DANI_ERR_CAPACITY, "match capacity %d too small for %d matches", cap, total);
+  return DANI_OK;
+}
+
 int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches) {
   LgContext* L = last_lg(e);
   if (!e || !L) return DANI_ERR_INVALID;

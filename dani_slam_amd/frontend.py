@@ -85,6 +85,8 @@ def load_library():
     lib.dani_sp_debug_layer.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int64]
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
+    lib.dani_lg_match_groups.argtypes = [C.c_void_p, _f, _f, C.c_int32, _f, _f, C.c_int32, C.c_int32, _i32, _i32, _i32, _i32, _f, _f,
+                                         C.c_float, _i32, _f, _i32, C.c_int32]
     lib.dani_lg_attention_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
     lib.dani_vocab_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32, _i32, _f, C.POINTER(C.c_double), _i32, C.POINTER(C.c_void_p)]
     lib.dani_vocab_destroy.argtypes = [C.c_void_p]
@@ -104,6 +106,8 @@ def load_library():
                                         C.c_int32, C.c_int32, C.POINTER(_FrontendParams), _f, _f, _f, C.c_int32, _i32, _i32,
                                         _i32, C.c_int32, _i32, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_reset.argtypes = [C.c_void_p, C.c_int32]
+    lib.dani_frontend_export_features.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, _i32]
+    lib.dani_frontend_match_resident.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_timings.argtypes = [C.c_void_p, _f]
     lib.dani_desc_best2.argtypes = [C.c_void_p, _f, C.c_int32, _f, C.c_int32, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32]
     lib.dani_host_distribute_octtree.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -360,6 +364,27 @@ class Engine:
         return self.lg_match_batch(pad(kpts0, 2), pad(desc0, 256), [n0], pad(kpts1, 2), pad(desc1, 256), [n1],
                                    size0, size1, threshold)[0]
 
+    def lg_match_groups(self, kpts0, desc0, kpts1, desc1, groups0, groups1, size0=None, size1=None, threshold=0.05):
+        """dani_lg_match_groups: groups0[g] / groups1[g] are the row lists of frame 0 / frame 1 matched in group g (one
+        vocabulary node in LGmatcher::SearchForTriangulation).  Returns a list (len G) of (matches [k,2] local to the
+        group's lists, scores [k])."""
+        k0 = np.ascontiguousarray(kpts0, np.float32).reshape(-1, 2); d0 = np.ascontiguousarray(desc0, np.float32).reshape(-1, 256)
+        k1 = np.ascontiguousarray(kpts1, np.float32).reshape(-1, 2); d1 = np.ascontiguousarray(desc1, np.float32).reshape(-1, 256)
+        G = len(groups0)
+        assert len(groups1) == G
+        off0 = np.zeros(G + 1, np.int32); off1 = np.zeros(G + 1, np.int32)
+        off0[1:] = np.cumsum([len(g) for g in groups0]); off1[1:] = np.cumsum([len(g) for g in groups1])
+        cat = lambda gs, n: np.ascontiguousarray(np.concatenate([np.asarray(g, np.int32).reshape(-1) for g in gs]) if n else np.zeros(1, np.int32), np.int32)
+        i0, i1 = cat(groups0, off0[G]), cat(groups1, off1[G])
+        cap = max(1, int(sum(min(len(a), len(b)) for a, b in zip(groups0, groups1))))
+        m = np.empty((cap, 2), np.int32); sc = np.empty(cap, np.float32); mo = np.zeros(G + 1, np.int32)
+        s0 = np.asarray(size0, np.float32) if size0 is not None else None
+        s1 = np.asarray(size1, np.float32) if size1 is not None else None
+        self._check(self.lib.dani_lg_match_groups(self.h, _fp(k0), _fp(d0), len(k0), _fp(k1), _fp(d1), len(k1), G, _ip(off0), _ip(i0),
+                                                  _ip(off1), _ip(i1), _fp(s0) if s0 is not None else None,
+                                                  _fp(s1) if s1 is not None else None, C.c_float(threshold), _ip(m), _fp(sc), _ip(mo), cap))
+        return [(m[mo[g]:mo[g + 1]].copy(), sc[mo[g]:mo[g + 1]].copy()) for g in range(G)]
+
     def lg_attention_profile(self):
         """(total ms, total algorithmic flop, launches) of the attention kernel in the last LightGlue call (profiling on)."""
         ms = C.c_float(0); fl = C.c_double(0); n = C.c_int32(0)
@@ -464,6 +489,39 @@ class Engine:
         if copy:
             res = [{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for r in res]
         return res
+
+    @staticmethod
+    def feature_slab_floats(cap):
+        """Size of the packed feature slab of dani_frontend_export_features: count, kpts [cap][2], desc [cap][256]."""
+        return 1 + cap * 258
+
+    def frontend_export_features(self, frame, cap, sequence=0, device_ptr=None):
+        """Pack resident frame `frame` of the last frontend_batch call of `sequence` into a slab (feature_slab_floats(cap)
+        floats): into the device buffer at `device_ptr` (returns the keypoint count), or into a new host array (returned)."""
+        n = C.c_int32(0)
+        if device_ptr is not None:
+            self._check(self.lib.dani_frontend_export_features(self.h, sequence, frame, C.c_void_p(device_ptr), 1, cap, C.byref(n)))
+            return n.value
+        slab = np.zeros(self.feature_slab_floats(cap), np.float32)
+        self._check(self.lib.dani_frontend_export_features(self.h, sequence, frame, slab.ctypes.data_as(C.c_void_p), 0, cap, C.byref(n)))
+        return slab
+
+    def frontend_match_resident(self, nframes, pred=None, pred_cap=0, pred_device_ptr=None, lg_threshold=0.05, cap=None, sequence=0):
+        """LightGlue over the frames the last frontend_batch(match_previous=False) call left resident: frame b against b-1,
+        frame 0 against `pred` (host slab array, or pred_device_ptr + pred_cap; None = the sequence's cached predecessor).
+        Returns a list of (matches [k,2], scores [k]) per frame."""
+        cap = cap or 4096
+        m = np.zeros((nframes, cap, 2), np.int32); sc = np.zeros((nframes, cap), np.float32); k = np.zeros(nframes, np.int32)
+        if pred_device_ptr is not None:
+            pp, on_dev = C.c_void_p(pred_device_ptr), 1
+        elif pred is not None:
+            pred = np.ascontiguousarray(pred, np.float32)
+            pred_cap = (pred.size - 1) // 258
+            pp, on_dev = pred.ctypes.data_as(C.c_void_p), 0
+        else:
+            pp, on_dev, pred_cap = None, 0, 0
+        self._check(self.lib.dani_frontend_match_resident(self.h, sequence, pp, on_dev, pred_cap, C.c_float(lg_threshold), _ip(m), _fp(sc), cap, _ip(k)))
+        return [(m[b, :k[b]].copy(), sc[b, :k[b]].copy()) for b in range(nframes)]
 
     def frontend_timings(self):
         ms = np.zeros(4, np.float32)

@@ -58,3 +58,27 @@ def allgather_features(kpts, resp, desc, cap: int, device=None):
         res.append((out[r, 1:1 + 2 * m].reshape(m, 2).copy(), out[r, 1 + 2 * cap:1 + 2 * cap + m].copy(),
                     out[r, 1 + 3 * cap:1 + 3 * cap + 256 * m].reshape(m, 256).copy()))
     return res
+
+
+def exchange_boundary_features(eng, last_frame: int, cap: int, device=None, sequence: int = 0):
+    """The one collective of BASELINE config #4 (one batch of consecutive frames sharded over the GPUs): every rank packs
+    the features of its LAST resident frame into a slab ON THE DEVICE (dani_frontend_export_features, no host round trip)
+    and one all-gather (RCCL over xGMI with backend "nccl": ~1 MB per rank, direct exchange) hands every rank all of
+    them; rank r matches its first frame against the slab of rank r-1 (rank 0: against the last rank's slab of the
+    previous step -- the caller keeps it).  With a gloo group (CPU rehearsal) the slab is staged through host memory.
+    Returns the gathered [world, slab] tensor (on `device` for nccl, on the CPU for gloo)."""
+    import torch
+    import torch.distributed as dist
+    nfl = eng.feature_slab_floats(cap)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    on_gpu = device is not None and (not dist.is_initialized() or dist.get_backend() == "nccl")
+    if on_gpu:
+        mine = torch.empty(nfl, dtype=torch.float32, device=device)
+        eng.frontend_export_features(last_frame, cap, sequence, device_ptr=mine.data_ptr())
+    else:
+        mine = torch.from_numpy(eng.frontend_export_features(last_frame, cap, sequence))
+    if world == 1:
+        return mine.reshape(1, nfl)
+    out = torch.empty(world * nfl, dtype=torch.float32, device=mine.device)
+    dist.all_gather_into_tensor(out, mine)
+    return out.reshape(world, nfl)

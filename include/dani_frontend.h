@@ -172,6 +172,25 @@ DANI_API int dani_lg_match_batch(dani_engine* e, int32_t P, int32_t in_cap, int3
                                  const int32_t* n1, const float* size0, const float* size1, float threshold,
                                  int32_t* matches, float* scores, int32_t cap, int32_t* k_out);
 
+/* Grouped variant for the per-vocabulary-node call shapes: G independent LightGlue problems over
+ * SUBSETS of two frames' features in ONE forward pass.  Replaces
+ *   - LGmatcher::SearchForTriangulation's loop, one matchDescriptors call per shared vocabulary node on the few
+ *     keypoints of that node without a map point (src/LGmatcher.cpp:905-983: hundreds of calls of 3-40 keypoints per
+ *     keyframe pair, each paying ~170 kernel launches), and
+ *   - the row-by-row gathers of LGmatcher::SearchByBoW (cv::Mat::push_back per keypoint, src/LGmatcher.cpp:257-288;
+ *     one group holding every gathered keypoint reproduces its single call at :314).
+ * Frame f in {0, 1}: kpts_f [n_f][2], desc_f [n_f][256] (host pointers: the keyframe's mvKeysUn / mDescriptors).
+ * Group g matches rows idx0[off0[g] .. off0[g+1]) of frame 0 (queries, in that order) against rows
+ * idx1[off1[g] .. off1[g+1]) of frame 1 -- exactly the kpsKF1 / descKF1 and kpsKF2 / descKF2 the reference builds per
+ * node.  size0 / size1 / threshold as dani_lg_match.  Outputs, CSR over the groups: match_offsets [G+1];
+ * matches [cap][2] = (queryIdx, trainIdx) LOCAL to the group's lists (the reference indexes f1it->second[m.queryIdx]);
+ * scores [cap].  A group with an empty side yields no matches (the reference skips the call, :970).  Returns
+ * DANI_ERR_CAPACITY with match_offsets[G] = needed count when cap is too small. */
+DANI_API int dani_lg_match_groups(dani_engine* e, const float* kpts0, const float* desc0, int32_t n0, const float* kpts1,
+                                  const float* desc1, int32_t n1, int32_t G, const int32_t* off0, const int32_t* idx0,
+                                  const int32_t* off1, const int32_t* idx1, const float* size0, const float* size1,
+                                  float threshold, int32_t* matches, float* scores, int32_t* match_offsets, int32_t cap);
+
 /* With dani_set_profiling(e, 1): summed duration (HIP events on the engine's stream) and algorithmic FLOP of the 18
  * attention-kernel launches of the last LightGlue call on this thread (bench.py roofline of the dominant kernel). */
 DANI_API int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches);
@@ -250,6 +269,22 @@ DANI_API int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t
                                  const dani_frontend_params* p, float* kpts_xy, float* resp, float* desc, int32_t cap,
                                  int32_t* n_out, int32_t* mono_index, int32_t* dyn_boxes, int32_t box_cap,
                                  int32_t* n_boxes, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out);
+/* Split form of the fused call for batches that are sharded over several GPUs (BASELINE config #4: ONE 64-frame batch,
+ * 8 frames per GPU): the pair (last frame of rank r-1, first frame of rank r) needs features that live on another GPU.
+ *   1. dani_frontend_batch with match_previous = 0 extracts and keeps the B frames' features resident; the cached
+ *      predecessor of the sequence is left as it is;
+ *   2. dani_frontend_export_features packs one resident frame (normally the last) into a caller-owned slab --
+ *      dst[0] = count, then kpts [cap][2], then desc [cap][256] (cap * 258 + 1 floats; host pointer, or DEVICE pointer with
+ *      dst_on_device != 0: the buffer the RCCL all-gather runs on, dani_slam_amd/sharding.py);
+ *   3. dani_frontend_match_resident runs LightGlue over the resident frames -- frame b against frame b-1, frame 0 against
+ *      `pred` (a slab in the layout of step 2, from the neighbouring rank; NULL = the sequence's own cached predecessor, as
+ *      the fused call uses) -- and then makes the last resident frame the sequence's predecessor.
+ * Outputs of step 3 as the match outputs of dani_frontend_batch.  Steps 1 + 3 with pred = NULL compute exactly what one
+ * fused call with match_previous = 1 computes. */
+DANI_API int dani_frontend_export_features(dani_engine* e, int32_t sequence, int32_t frame, float* dst, int32_t dst_on_device,
+                                           int32_t cap, int32_t* n_out);
+DANI_API int dani_frontend_match_resident(dani_engine* e, int32_t sequence, const float* pred, int32_t pred_on_device, int32_t pred_cap,
+                                          float lg_threshold, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out);
 /* Forget the cached previous frame (start of a new sequence). */
 DANI_API int dani_frontend_reset(dani_engine* e, int32_t sequence);
 /* Stage wall times (ms) of the last dani_frontend_batch on this thread: [0] yolo, [1] superpoint, [2] lightglue, [3] total. */

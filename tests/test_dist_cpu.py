@@ -40,6 +40,24 @@ def _worker(rank, world, port, q):
             nn = 5 + 3 * rr
             ek = g.rand(nn, 2).astype(np.float32); er = g.rand(nn).astype(np.float32); ed = g.rand(nn, 256).astype(np.float32)
             ok = ok and np.array_equal(allf[rr][0], ek) and np.array_equal(allf[rr][1], er) and np.array_equal(allf[rr][2], ed)
+        # the shard-boundary exchange of bench.py (N > 1): every rank packs its last frame, one all-gather, rank r reads r-1
+        class FakeEngine:   # stands in for frontend.Engine (no GPU here): same slab layout as dani_frontend_export_features
+            @staticmethod
+            def feature_slab_floats(cap): return 1 + cap * 258
+            def frontend_export_features(self, frame, cap, sequence=0, device_ptr=None):
+                assert device_ptr is None and frame == 7
+                slab = np.zeros(self.feature_slab_floats(cap), np.float32)
+                slab[0] = n; slab[1:1 + 2 * n] = k.reshape(-1); slab[1 + 2 * cap:1 + 2 * cap + 256 * n] = d.reshape(-1)
+                return slab
+        slabs = sharding.exchange_boundary_features(FakeEngine(), 7, 16, None)
+        ok = ok and tuple(slabs.shape) == (world, 1 + 16 * 258)
+        for rr in range(world):
+            g = np.random.RandomState(100 + rr)
+            nn = 5 + 3 * rr
+            ek = g.rand(nn, 2).astype(np.float32); g.rand(nn); ed = g.rand(nn, 256).astype(np.float32)
+            row = slabs[rr].numpy()
+            ok = ok and int(row[0]) == nn and np.array_equal(row[1:1 + 2 * nn].reshape(nn, 2), ek)
+            ok = ok and np.array_equal(row[1 + 32:1 + 32 + 256 * nn].reshape(nn, 256), ed)
         mx = sharding.reduce_max_seconds(1.0 + rank)
         frames = list(sharding.shard_frames(16, rank, world))
         q.put((rank, ok, mx, frames))

@@ -165,3 +165,48 @@ def test_stereo_pair_mode(sp_weights):
     with pytest.raises(frontend.DaniError):
         e.frontend_batch(gray[:3], None, nfeatures=NF, use_yolo=False, stereo_pairs=True)      # odd number of frames
     e.close()
+
+
+def test_split_form_equals_fused_call_and_takes_a_foreign_predecessor(sp_weights):
+    """dani_frontend_batch(match_previous = 0) + dani_frontend_export_features + dani_frontend_match_resident: the form a
+    batch sharded over several GPUs needs (the pair that crosses a shard boundary gets its predecessor from another rank).
+    With the sequence's own predecessor it must equal the fused call; with a foreign slab, the same as if the frames had
+    been one sequence -- host slab and device slab alike."""
+    import torch
+    from dani_slam_amd import frontend
+    w = synth.bench_weights()
+    e = frontend.Engine(device=0, max_batch=4, weights=w)
+    e.yolo_set_classes(yo.COCO_NAMES, yo.DYNAMIC_NAMES)
+    gray, bgr = synth.bench_frames(range(8))
+    fused = e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF) + e.frontend_batch(gray[4:], bgr[4:], nfeatures=NF)
+    assert min(len(o["matches"]) for o in fused[1:]) >= 20
+    cap = NF + 12
+
+    def same(a, b):
+        return np.array_equal(a[0], b["matches"]) and np.allclose(a[1], b["scores"], rtol=0, atol=1e-6)
+    # own predecessor: extract + match_resident == fused, over two calls
+    e.frontend_reset()
+    x0 = e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False)
+    assert all(len(o["matches"]) == 0 for o in x0) and all(np.array_equal(a["kpts"], b["kpts"]) for a, b in zip(x0, fused[:4]))
+    m0 = e.frontend_match_resident(4, cap=cap)
+    slab3 = e.frontend_export_features(3, cap)                       # frame 3's features, packed on the host
+    assert int(slab3[0]) == len(fused[3]["kpts"]) and np.array_equal(slab3[1:1 + 2 * int(slab3[0])].reshape(-1, 2), fused[3]["kpts"])
+    x1 = e.frontend_batch(gray[4:], bgr[4:], nfeatures=NF, match_previous=False)
+    m1 = e.frontend_match_resident(4, cap=cap)                       # predecessor = frame 3, cached by the previous match
+    assert all(same(m, f) for m, f in zip(m0 + m1, fused))
+    # foreign predecessor: another engine state ("another rank") extracts frames 4..7 and is handed frame 3's slab
+    e.frontend_reset()
+    e.frontend_batch(gray[4:], bgr[4:], nfeatures=NF, match_previous=False)
+    assert all(same(m, f) for m, f in zip(e.frontend_match_resident(4, pred=slab3, cap=cap), fused[4:]))
+    d_slab = torch.from_numpy(slab3).cuda()                          # ... and the same slab resident in HBM (the all-gather's output)
+    e.frontend_reset()
+    e.frontend_batch(gray[4:], bgr[4:], nfeatures=NF, match_previous=False)
+    assert all(same(m, f) for m, f in zip(e.frontend_match_resident(4, pred_device_ptr=d_slab.data_ptr(), pred_cap=cap, cap=cap), fused[4:]))
+    # export straight into a device buffer == the host export
+    d_out = torch.zeros(e.feature_slab_floats(cap), dtype=torch.float32, device="cuda")
+    n = e.frontend_export_features(3, cap, device_ptr=d_out.data_ptr())
+    ref7 = e.frontend_export_features(3, cap)
+    got = d_out.cpu().numpy()
+    assert n == int(ref7[0]) and np.array_equal(got[:1 + 2 * n], ref7[:1 + 2 * n])
+    assert np.array_equal(got[1 + 2 * cap:1 + 2 * cap + 256 * n], ref7[1 + 2 * cap:1 + 2 * cap + 256 * n])
+    e.close()

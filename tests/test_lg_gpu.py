@@ -193,3 +193,52 @@ def test_missing_lg_weights_is_loud(sp_weights):
         e.lg_match(k0, d0, k1, d1, SIZE, SIZE)
     assert ei.value.code == frontend.DANI_ERR_WEIGHTS
     e.close()
+
+
+def test_match_groups_many_small_ragged_sets(lg_weights, sp_weights):
+    """dani_lg_match_groups (SURVEY row a16): the per-vocabulary-node call shape of LGmatcher::SearchForTriangulation
+    (src/LGmatcher.cpp:905-983) -- a few hundred independent problems of 3-40 keypoints -- in ONE forward pass, every
+    group against the oracle run on that group alone; plus empty-sided groups and the one-group SearchByBoW shape."""
+    from dani_slam_amd import frontend
+    w = dict(sp_weights); w.update(lg_weights)
+    e = frontend.Engine(device=0, weights=w, max_batch=2)
+    k0, d0, k1, d1, gt = synth.matching_pair(321, n0=4200, n1=4100, overlap=0.7)
+    rng = np.random.RandomState(5)
+    G = 240
+    node0 = rng.randint(0, G, len(k0)); node1 = rng.randint(0, G, len(k1))
+    has = gt >= 0
+    same = has & (rng.rand(len(k0)) < 0.9)
+    node1[gt[same]] = node0[same]                       # corresponding points mostly share their vocabulary node
+    groups0 = [np.nonzero(node0 == g)[0][:40] for g in range(G)]
+    groups1 = [np.nonzero(node1 == g)[0][:40] for g in range(G)]
+    for g in range(0, G, 7):                            # thin some groups down to 3..6 keypoints, shuffle the row order
+        groups0[g] = rng.permutation(groups0[g])[:3 + g % 4]; groups1[g] = rng.permutation(groups1[g])[:3 + (g // 7) % 4]
+    groups0[11] = groups0[11][:0]; groups1[12] = groups1[12][:0]      # empty sides: no call in the reference (:970)
+    sizes = [len(a) for a in groups0] + [len(b) for b in groups1]
+    assert min(s for s in sizes if s) == 3 and max(sizes) <= 40 and G >= 200
+    res = e.lg_match_groups(k0, d0, k1, d1, groups0, groups1, SIZE, SIZE, 0.05)
+    assert len(res) == G and len(res[11][0]) == 0 and len(res[12][0]) == 0
+    total = wrong = 0
+    for g in range(G):
+        a, b = groups0[g], groups1[g]
+        if len(a) == 0 or len(b) == 0:
+            continue
+        mo, so = lg.match_descriptors(lg_weights, k0[a], d0[a], k1[b], d1[b], SIZE, SIZE, 0.05)
+        want = {tuple(x): float(v) for x, v in zip(mo.tolist(), so)}
+        got = {tuple(x): float(v) for x, v in zip(res[g][0].tolist(), res[g][1])}
+        total += len(want); wrong += len(set(want) ^ set(got))
+        assert all(abs(got[c] - want[c]) < 1e-3 for c in set(got) & set(want)), g
+        assert all(0 <= i < len(a) and 0 <= j < len(b) for i, j in got), g                  # indices are local to the group
+    assert total > 500 and wrong <= max(2, total // 100), (total, wrong)                    # near-tie flips only
+    # the groups agree with single calls through the plain entry point (same kernels, other batch geometry)
+    for g in (0, 7, 100):
+        m, s = e.lg_match(k0[groups0[g]], d0[groups0[g]], k1[groups1[g]], d1[groups1[g]], SIZE, SIZE, 0.05)
+        assert np.array_equal(m, res[g][0]) and np.allclose(s, res[g][1], rtol=0, atol=1e-5)
+    # SearchByBoW's shape: ONE group holding everything that was gathered (src/LGmatcher.cpp:257-314)
+    rows0 = np.nonzero(node0 < 60)[0]; rows1 = np.nonzero(node1 < 60)[0]
+    one = e.lg_match_groups(k0, d0, k1, d1, [rows0], [rows1], SIZE, SIZE, 0.05)[0]
+    m, s = e.lg_match(k0[rows0], d0[rows0], k1[rows1], d1[rows1], SIZE, SIZE, 0.05)
+    assert len(m) > 100 and np.array_equal(one[0], m) and np.allclose(one[1], s, rtol=0, atol=1e-6)
+    with pytest.raises(frontend.DaniError):
+        e.lg_match_groups(k0, d0, k1, d1, [np.array([len(k0)])], [np.array([0])], SIZE, SIZE)   # row index out of range
+    e.close()
