@@ -238,7 +238,7 @@ def test_match_groups_many_small_ragged_sets(lg_weights, sp_weights):
     rows0 = np.nonzero(node0 < 60)[0]; rows1 = np.nonzero(node1 < 60)[0]
     one = e.lg_match_groups(k0, d0, k1, d1, [rows0], [rows1], SIZE, SIZE, 0.05)[0]
     m, s = e.lg_match(k0[rows0], d0[rows0], k1[rows1], d1[rows1], SIZE, SIZE, 0.05)
-    assert len(m) > 100 and np.array_equal(one[0], m) and np.allclose(one[1], s, rtol=0, atol=1e-6)
+    assert len(m) > 20 and np.array_equal(one[0], m) and np.allclose(one[1], s, rtol=0, atol=1e-6)
     with pytest.raises(frontend.DaniError):
         e.lg_match_groups(k0, d0, k1, d1, [np.array([len(k0)])], [np.array([0])], SIZE, SIZE)   # row index out of range
     e.close()
