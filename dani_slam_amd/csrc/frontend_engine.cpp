@@ -316,15 +316,16 @@ int dani_frontend_match_resident(dani_engine* e, int32_t sequence, const float* 
 // ================================================================================================
 namespace {
 
+// rt_desc / rt_level: the train set already in HBM (a retained frame): t_desc / t_level are then not uploaded
 int desc_scan(dani_engine* e, const float* q_desc, int32_t nq, const float* t_desc, int32_t nt, const int32_t* t_level,
               const int32_t* cand_offsets, const int32_t* cand_idx, float* best_dist, float* best_dist2, int32_t* best_idx,
-              int32_t* best_level, int32_t* best_level2, float* cand_dist) {
+              int32_t* best_level, int32_t* best_level2, float* cand_dist, const float* rt_desc = nullptr, const int32_t* rt_level = nullptr) {
   if (!e) return DANI_ERR_INVALID;
   if (nq < 0 || nt < 0 || (nq && (!q_desc || !cand_offsets || !best_dist || !best_dist2 || !best_idx || !best_level || !best_level2)))
     return fail(e, DANI_ERR_INVALID, "bad dani_desc_best2 argument");
   if (nq == 0) return DANI_OK;
   const int total = cand_offsets[nq];
-  if (total < 0 || (total && (!cand_idx || !t_desc))) return fail(e, DANI_ERR_INVALID, "bad candidate lists");
+  if (total < 0 || (total && (!cand_idx || (!t_desc && !rt_desc)))) return fail(e, DANI_ERR_INVALID, "bad candidate lists");
   for (int i = 0; i < total; i++)
     if (cand_idx[i] < 0 || cand_idx[i] >= nt) return fail(e, DANI_ERR_INVALID, "candidate index %d outside [0, %d)", cand_idx[i], nt);
   HIP_TRY(e, hipSetDevice(e->device));
@@ -332,7 +333,7 @@ int desc_scan(dani_engine* e, const float* q_desc, int32_t nq, const float* t_de
   if (!c) return fail(e, DANI_ERR_INVALID, "all contexts busy");
   struct Releaser { dani_engine* e; Context* c; ~Releaser() { release(e, c); } } rel{e, c};
   hipStream_t s = c->stream;
-  const size_t bq = (size_t)nq * 1024, bt = (size_t)std::max(nt, 1) * 1024, bl = (size_t)std::max(nt, 1) * 4;
+  const size_t bq = (size_t)nq * 1024, bt = rt_desc ? 1024 : (size_t)std::max(nt, 1) * 1024, bl = (size_t)std::max(nt, 1) * 4;
   const size_t bo = (size_t)(nq + 1) * 4, bc = (size_t)std::max(total, 1) * 4, bout = (size_t)nq * 4;
   const size_t need = bq + bt + bl + bo + 2 * bc + 5 * bout;   // ... + per-candidate distances
   if (need > c->scan_ws_bytes) {   // grow-only: a tracking thread calls this every frame with similar sizes
@@ -347,11 +348,11 @@ int desc_scan(dani_engine* e, const float* q_desc, int32_t nq, const float* t_de
   char* o = d + bq + bt + bl + bo + bc;
   float* dcd = (float*)(o + 5 * bout);
   HIP_TRY(e, hipMemcpyAsync(dq, q_desc, bq, hipMemcpyHostToDevice, s));
-  if (nt) HIP_TRY(e, hipMemcpyAsync(dt, t_desc, (size_t)nt * 1024, hipMemcpyHostToDevice, s));
-  if (t_level && nt) HIP_TRY(e, hipMemcpyAsync(dl, t_level, (size_t)nt * 4, hipMemcpyHostToDevice, s));
+  if (nt && !rt_desc) HIP_TRY(e, hipMemcpyAsync(dt, t_desc, (size_t)nt * 1024, hipMemcpyHostToDevice, s));
+  if (t_level && nt && !rt_desc) HIP_TRY(e, hipMemcpyAsync(dl, t_level, (size_t)nt * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(e, hipMemcpyAsync(doff, cand_offsets, bo, hipMemcpyHostToDevice, s));
   if (total) HIP_TRY(e, hipMemcpyAsync(dci, cand_idx, (size_t)total * 4, hipMemcpyHostToDevice, s));
-  launch_desc_best2(dq, dt, t_level ? dl : nullptr, doff, dci, nq, (float*)o, (float*)(o + bout), (int32_t*)(o + 2 * bout),
+  launch_desc_best2(dq, rt_desc ? rt_desc : dt, rt_desc ? rt_level : (t_level ? dl : nullptr), doff, dci, nq, (float*)o, (float*)(o + bout), (int32_t*)(o + 2 * bout),
                     (int32_t*)(o + 3 * bout), (int32_t*)(o + 4 * bout), cand_dist ? dcd : nullptr, s);
   HIP_TRY(e, hipGetLastError());
   HIP_TRY(e, hipMemcpyAsync(best_dist, o, bout, hipMemcpyDeviceToHost, s));
@@ -469,11 +470,11 @@ void dani_vocab_destroy(dani_vocab* v) {
   delete v;
 }
 
-int dani_bow_transform(dani_engine* e, dani_vocab* v, const float* feats, int32_t n, int32_t levelsup, int32_t weighting, int32_t norm,
+static int bow_transform_impl(dani_engine* e, dani_vocab* v, const float* feats, const float* d_resident, int32_t n, int32_t levelsup, int32_t weighting, int32_t norm,
                        int32_t* word_ids, double* word_values, int32_t* n_words, int32_t* fv_node_ids, int32_t* fv_offsets,
                        int32_t* fv_features, int32_t* n_fv_nodes) {
   if (!e) return DANI_ERR_INVALID;
-  if (!v || v->e != e || n < 0 || (n && !feats) || weighting < 0 || weighting > 3 || norm < 0 || norm > 2 || !word_ids || !word_values || !n_words ||
+  if (!v || v->e != e || n < 0 || (n && !feats && !d_resident) || weighting < 0 || weighting > 3 || norm < 0 || norm > 2 || !word_ids || !word_values || !n_words ||
       !fv_node_ids || !fv_offsets || !fv_features || !n_fv_nodes) return fail(e, DANI_ERR_INVALID, "bad dani_bow_transform argument");
   *n_words = 0; *n_fv_nodes = 0; fv_offsets[0] = 0;
   if (n == 0) return DANI_OK;
@@ -491,8 +492,8 @@ int dani_bow_transform(dani_engine* e, dani_vocab* v, const float* feats, int32_
     HIP_TRY(e, hipMalloc((void**)&v->d_out, (size_t)n * 8));
     v->cap = n;
   }
-  HIP_TRY(e, hipMemcpyAsync(v->d_feats, feats, (size_t)n * 1024, hipMemcpyHostToDevice, s));
-  launch_bow_descend(v->d_feats, n, v->d_child_off, v->d_child_ids, v->d_desc, v->L - levelsup, v->d_out, v->d_out + n, s);
+  if (!d_resident) HIP_TRY(e, hipMemcpyAsync(v->d_feats, feats, (size_t)n * 1024, hipMemcpyHostToDevice, s));
+  launch_bow_descend(d_resident ? d_resident : v->d_feats, n, v->d_child_off, v->d_child_ids, v->d_desc, v->L - levelsup, v->d_out, v->d_out + n, s);
   HIP_TRY(e, hipGetLastError());
   std::vector<int32_t> leaf_nid((size_t)2 * n);
   HIP_TRY(e, hipMemcpyAsync(leaf_nid.data(), v->d_out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
@@ -528,6 +529,193 @@ int dani_bow_transform(dani_engine* e, dani_vocab* v, const float* feats, int32_
   }
   *n_fv_nodes = m;
   return DANI_OK;
+}
+
+int dani_bow_transform(dani_engine* e, dani_vocab* v, const float* feats, int32_t n, int32_t levelsup, int32_t weighting, int32_t norm,
+                       int32_t* word_ids, double* word_values, int32_t* n_words, int32_t* fv_node_ids, int32_t* fv_offsets,
+                       int32_t* fv_features, int32_t* n_fv_nodes) {
+  return bow_transform_impl(e, v, feats, nullptr, n, levelsup, weighting, norm, word_ids, word_values, n_words, fv_node_ids, fv_offsets,
+                            fv_features, n_fv_nodes);
+}
+
+/* ---- device-resident consumers: retained frames (SURVEY 8f, ranks 1-3 without the PCIe bounce) --------------------- */
+
+struct dani_features {
+  dani_engine* e = nullptr;
+  int n = 0;
+  float* d_kxy = nullptr;       // [n][2] coordinates used by the grid and the window tests (undistorted when supplied)
+  float* d_desc = nullptr;      // [n][256]
+  int32_t* d_octave = nullptr;  // [n]
+  bool has_grid = false;
+  dani_grid grid{};
+  int32_t* d_cell_offsets = nullptr; int32_t* d_cell_idx = nullptr;
+  std::mutex mu;                // the per-call scratch below
+  char* ws = nullptr; size_t ws_bytes = 0;
+};
+
+void dani_features_release(dani_features* f) {
+  if (!f) return;
+  if (f->e) (void)hipSetDevice(f->e->device);
+  for (void* p : {(void*)f->d_kxy, (void*)f->d_desc, (void*)f->d_octave, (void*)f->d_cell_offsets, (void*)f->d_cell_idx, (void*)f->ws})
+    if (p) (void)hipFree(p);
+  delete f;
+}
+
+int dani_features_count(const dani_features* f) { return f ? f->n : DANI_ERR_INVALID; }
+
+int dani_frontend_retain(dani_engine* e, int32_t sequence, int32_t frame, const float* kpts_un, const int32_t* octave, const dani_grid* grid,
+                         dani_features** out) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!out || (grid && (grid->cols < 1 || grid->rows < 1 || (int64_t)grid->cols * grid->rows > (1 << 20))))
+    return fail(e, DANI_ERR_INVALID, "bad dani_frontend_retain argument");
+  *out = nullptr;
+  SeqState* S = seq_state(e, sequence);
+  std::lock_guard<std::mutex> seq_lock(S->mu);
+  Context* c = S->ctx;
+  if (!c || frame < 0 || frame >= S->res_B) return fail(e, DANI_ERR_INVALID, "sequence %d holds no resident frame %d", sequence, frame);
+  HIP_TRY(e, hipSetDevice(e->device));
+  const int n = S->res_n[frame], m = std::max(n, 1);
+  dani_features* f = new dani_features();
+  f->e = e; f->n = n;
+  auto bail = [&](const char* what) { dani_features_release(f); return fail(e, DANI_ERR_HIP, "%s failed (retain)", what); };
+  if (hipMalloc((void**)&f->d_kxy, (size_t)m * 8) != hipSuccess || hipMalloc((void**)&f->d_desc, (size_t)m * 1024) != hipSuccess ||
+      hipMalloc((void**)&f->d_octave, (size_t)m * 4) != hipSuccess) return bail("hipMalloc");
+  hipStream_t s = c->stream;
+  if (n) {
+    if (hipMemcpyAsync(f->d_desc, c->d_descout + (size_t)frame * c->kcap * 256, (size_t)n * 1024, hipMemcpyDeviceToDevice, s) != hipSuccess) return bail("descriptor copy");
+    if ((kpts_un ? hipMemcpyAsync(f->d_kxy, kpts_un, (size_t)n * 8, hipMemcpyHostToDevice, s)
+                 : hipMemcpyAsync(f->d_kxy, c->d_kimg + (size_t)frame * c->kcap * 2, (size_t)n * 8, hipMemcpyDeviceToDevice, s)) != hipSuccess) return bail("keypoint copy");
+    if ((octave ? hipMemcpyAsync(f->d_octave, octave, (size_t)n * 4, hipMemcpyHostToDevice, s) : hipMemsetAsync(f->d_octave, 0, (size_t)n * 4, s)) != hipSuccess) return bail("octave copy");
+  }
+  if (grid) {
+    const int ncells = grid->cols * grid->rows;
+    int32_t* cell_of = nullptr;
+    if (hipMalloc((void**)&f->d_cell_offsets, (size_t)(ncells + 1) * 4) != hipSuccess || hipMalloc((void**)&f->d_cell_idx, (size_t)m * 4) != hipSuccess ||
+        hipMalloc((void**)&cell_of, (size_t)m * 4) != hipSuccess) { if (cell_of) (void)hipFree(cell_of); return bail("hipMalloc"); }
+    launch_grid_assign(f->d_kxy, n, grid->min_x, grid->min_y, grid->inv_w, grid->inv_h, grid->cols, grid->rows, cell_of, f->d_cell_offsets, f->d_cell_idx, s);
+    const hipError_t st = hipStreamSynchronize(s);
+    (void)hipFree(cell_of);
+    if (st != hipSuccess || hipGetLastError() != hipSuccess) return bail("grid kernel");
+    f->grid = *grid; f->has_grid = true;
+  } else if (hipStreamSynchronize(s) != hipSuccess) return bail("copy");
+  *out = f;
+  return DANI_OK;
+}
+
+int dani_features_fetch_grid(dani_features* f, int32_t* cell_offsets, int32_t* cell_idx) {
+  if (!f || !f->has_grid || !cell_offsets) return DANI_ERR_INVALID;
+  (void)hipSetDevice(f->e->device);
+  const int ncells = f->grid.cols * f->grid.rows;
+  if (hipMemcpy(cell_offsets, f->d_cell_offsets, (size_t)(ncells + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) return DANI_ERR_HIP;
+  const int total = cell_offsets[ncells];
+  if (total && cell_idx && hipMemcpy(cell_idx, f->d_cell_idx, (size_t)total * 4, hipMemcpyDeviceToHost) != hipSuccess) return DANI_ERR_HIP;
+  return total;
+}
+
+int dani_desc_scan_resident(dani_engine* e, const float* q_desc, int32_t nq, const dani_features* train, const int32_t* cand_offsets,
+                            const int32_t* cand_idx, float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
+                            int32_t* best_level2, float* cand_dist) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!train || train->e != e) return fail(e, DANI_ERR_INVALID, "bad retained frame");
+  return desc_scan(e, q_desc, nq, nullptr, train->n, nullptr, cand_offsets, cand_idx, best_dist, best_dist2, best_idx, best_level, best_level2,
+                   cand_dist, train->d_desc, train->d_octave);
+}
+
+int dani_search_windows_resident(dani_engine* e, const dani_features* train_c, const float* q_desc, int32_t nq, const float* qx, const float* qy,
+                                 const float* qr, const int32_t* min_level, const int32_t* max_level, float* best_dist, float* best_dist2,
+                                 int32_t* best_idx, int32_t* best_level, int32_t* best_level2, int32_t* cand_offsets, int32_t* cand_idx,
+                                 float* cand_dist, int32_t cand_cap) {
+  if (!e) return DANI_ERR_INVALID;
+  dani_features* f = const_cast<dani_features*>(train_c);
+  if (!f || f->e != e || !f->has_grid) return fail(e, DANI_ERR_INVALID, "the retained frame has no grid (pass one to dani_frontend_retain)");
+  if (nq < 0 || (nq && (!q_desc || !qx || !qy || !qr || !best_dist || !best_dist2 || !best_idx || !best_level || !best_level2)) || cand_cap < 0 ||
+      (cand_cap && (!cand_offsets || !cand_idx))) return fail(e, DANI_ERR_INVALID, "bad dani_search_windows_resident argument");
+  if (nq == 0) { if (cand_offsets) cand_offsets[0] = 0; return DANI_OK; }
+  HIP_TRY(e, hipSetDevice(e->device));
+  std::lock_guard<std::mutex> lk(f->mu);
+  CtxLease lease(e, nullptr);
+  Context* c = lease.c;
+  hipStream_t s = c->stream;
+  // scratch: q_desc | qx qy qr | levels | counts | offsets | outputs(5) ; candidates (idx + dist) grow separately
+  const size_t bq = (size_t)nq * 1024, b4 = (size_t)nq * 4, boff = (size_t)(nq + 1) * 4;
+  const size_t fixed = bq + 3 * b4 + 2 * b4 + b4 + boff + 5 * b4 + 256;
+  const size_t cand_room = (size_t)std::max(f->n, 1) * 64 * 8;     // first guess: 64 candidates per query ... grown below when short
+  auto ensure = [&](size_t need) -> int {
+    if (need <= f->ws_bytes) return 0;
+    if (f->ws) (void)hipFree(f->ws);
+    f->ws = nullptr; f->ws_bytes = 0;
+    HIP_TRY(e, hipMalloc((void**)&f->ws, need));
+    f->ws_bytes = need;
+    return 0;
+  };
+  int rc = ensure(fixed + std::max(cand_room, (size_t)nq * 32 * 8));
+  if (rc) return rc;
+  auto carve = [&](char* base) {
+    struct P { float *q, *qx, *qy, *qr; int32_t *minl, *maxl, *counts, *offs; char* out; char* cand; } p;
+    p.q = (float*)base; char* w = base + bq;
+    p.qx = (float*)w; w += b4; p.qy = (float*)w; w += b4; p.qr = (float*)w; w += b4;
+    p.minl = (int32_t*)w; w += b4; p.maxl = (int32_t*)w; w += b4; p.counts = (int32_t*)w; w += b4;
+    p.offs = (int32_t*)w; w += boff; w = (char*)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+    p.out = w; w += 5 * b4; w = (char*)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+    p.cand = w;
+    return p;
+  };
+  auto P = carve(f->ws);
+  const dani_grid& g = f->grid;
+  auto upload = [&]() -> int {
+    HIP_TRY(e, hipMemcpyAsync(P.q, q_desc, bq, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(P.qx, qx, b4, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(P.qy, qy, b4, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemcpyAsync(P.qr, qr, b4, hipMemcpyHostToDevice, s));
+    if (min_level) HIP_TRY(e, hipMemcpyAsync(P.minl, min_level, b4, hipMemcpyHostToDevice, s));
+    if (max_level) HIP_TRY(e, hipMemcpyAsync(P.maxl, max_level, b4, hipMemcpyHostToDevice, s));
+    return 0;
+  };
+  if ((rc = upload())) return rc;
+  launch_area_count(f->d_kxy, f->d_octave, g.min_x, g.min_y, g.inv_w, g.inv_h, g.cols, g.rows, f->d_cell_offsets, f->d_cell_idx, P.qx, P.qy, P.qr,
+                    min_level ? P.minl : nullptr, max_level ? P.maxl : nullptr, nq, P.counts, P.offs, s);
+  int32_t total = 0;
+  HIP_TRY(e, hipMemcpyAsync(&total, P.offs + nq, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipStreamSynchronize(s));
+  HIP_TRY(e, hipGetLastError());
+  const size_t need = fixed + (size_t)std::max(total, 1) * 8 + 64;
+  if (need > f->ws_bytes) {          // rare: more candidates than the first guess -> regrow and redo the (cheap) count pass
+    if ((rc = ensure(need + need / 4))) return rc;
+    P = carve(f->ws);
+    if ((rc = upload())) return rc;
+    launch_area_count(f->d_kxy, f->d_octave, g.min_x, g.min_y, g.inv_w, g.inv_h, g.cols, g.rows, f->d_cell_offsets, f->d_cell_idx, P.qx, P.qy, P.qr,
+                      min_level ? P.minl : nullptr, max_level ? P.maxl : nullptr, nq, P.counts, P.offs, s);
+  }
+  int32_t* d_cidx = (int32_t*)P.cand;
+  float* d_cdist = (float*)(P.cand + (size_t)std::max(total, 1) * 4);
+  launch_area_fill(f->d_kxy, f->d_octave, g.min_x, g.min_y, g.inv_w, g.inv_h, g.cols, g.rows, f->d_cell_offsets, f->d_cell_idx, P.qx, P.qy, P.qr,
+                   min_level ? P.minl : nullptr, max_level ? P.maxl : nullptr, nq, P.offs, d_cidx, s);
+  launch_desc_best2(P.q, f->d_desc, f->d_octave, P.offs, d_cidx, nq, (float*)P.out, (float*)(P.out + b4), (int32_t*)(P.out + 2 * b4),
+                    (int32_t*)(P.out + 3 * b4), (int32_t*)(P.out + 4 * b4), (cand_dist && cand_cap) ? d_cdist : nullptr, s);
+  HIP_TRY(e, hipGetLastError());
+  HIP_TRY(e, hipMemcpyAsync(best_dist, P.out, b4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(best_dist2, P.out + b4, b4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(best_idx, P.out + 2 * b4, b4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(best_level, P.out + 3 * b4, b4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(best_level2, P.out + 4 * b4, b4, hipMemcpyDeviceToHost, s));
+  const bool lists = cand_cap > 0 && total <= cand_cap;
+  if (cand_offsets) HIP_TRY(e, hipMemcpyAsync(cand_offsets, P.offs, boff, hipMemcpyDeviceToHost, s));
+  if (lists && total) {
+    HIP_TRY(e, hipMemcpyAsync(cand_idx, d_cidx, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+    if (cand_dist) HIP_TRY(e, hipMemcpyAsync(cand_dist, d_cdist, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(e, hipStreamSynchronize(s));
+  if (cand_cap > 0 && total > cand_cap) return fail(e, DANI_ERR_CAPACITY, "%d candidates (> %d)", total, cand_cap);
+  return DANI_OK;
+}
+
+int dani_bow_transform_resident(dani_engine* e, dani_vocab* v, const dani_features* f, int32_t levelsup, int32_t weighting, int32_t norm,
+                                int32_t* word_ids, double* word_values, int32_t* n_words, int32_t* fv_node_ids, int32_t* fv_offsets,
+                                int32_t* fv_features, int32_t* n_fv_nodes) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!f || f->e != e) return fail(e, DANI_ERR_INVALID, "bad retained frame");
+  return bow_transform_impl(e, v, nullptr, f->d_desc, f->n, levelsup, weighting, norm, word_ids, word_values, n_words, fv_node_ids, fv_offsets,
+                            fv_features, n_fv_nodes);
 }
 
 }  // extern "C"

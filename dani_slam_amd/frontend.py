@@ -85,6 +85,16 @@ def load_library():
     lib.dani_sp_debug_layer.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int64]
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
+    lib.dani_frontend_retain.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, _i32, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.dani_features_release.argtypes = [C.c_void_p]
+    lib.dani_features_release.restype = None
+    lib.dani_features_count.argtypes = [C.c_void_p]
+    lib.dani_features_fetch_grid.argtypes = [C.c_void_p, _i32, _i32]
+    lib.dani_desc_scan_resident.argtypes = [C.c_void_p, _f, C.c_int32, C.c_void_p, _i32, _i32, _f, _f, _i32, _i32, _i32, _f]
+    lib.dani_search_windows_resident.argtypes = [C.c_void_p, C.c_void_p, _f, C.c_int32, _f, _f, _f, _i32, _i32, _f, _f, _i32, _i32, _i32,
+                                                 _i32, _i32, _f, C.c_int32]
+    lib.dani_bow_transform_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _i32, C.POINTER(C.c_double),
+                                                _i32, _i32, _i32, _i32, _i32]
     lib.dani_lg_match_groups.argtypes = [C.c_void_p, _f, _f, C.c_int32, _f, _f, C.c_int32, C.c_int32, _i32, _i32, _i32, _i32, _f, _f,
                                          C.c_float, _i32, _f, _i32, C.c_int32]
     lib.dani_lg_attention_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
@@ -595,6 +605,73 @@ class Engine:
         fn = np.zeros(max(n, 1), np.int32); fo = np.zeros(n + 1, np.int32); ff = np.zeros(max(n, 1), np.int32); nf = C.c_int32(0)
         self._check(self.lib.dani_bow_transform(self.h, vocab, _fp(f), n, levelsup, weighting, norm, _ip(wid), wv.ctypes.data_as(C.POINTER(C.c_double)),
                                                 C.byref(nw), _ip(fn), _ip(fo), _ip(ff), C.byref(nf)))
+        bow = {int(wid[i]): float(wv[i]) for i in range(nw.value)}
+        fv = {int(fn[i]): ff[fo[i]:fo[i + 1]].tolist() for i in range(nf.value)}
+        return bow, fv
+
+    # -- device-resident consumers (SURVEY 8f without the PCIe bounce) ----------------------------------
+    def frontend_retain(self, frame, sequence=0, kpts_un=None, octave=None, grid=None):
+        """Keep frame `frame` of the last frontend_batch call in HBM (dani_frontend_retain).  grid = (min_x, min_y, inv_w,
+        inv_h, cols, rows) builds Frame::AssignFeaturesToGrid's lists on the device.  Returns an opaque handle."""
+        h = C.c_void_p()
+        ku = np.ascontiguousarray(kpts_un, np.float32) if kpts_un is not None else None
+        oc = np.ascontiguousarray(octave, np.int32) if octave is not None else None
+        g = _Grid(*grid) if grid is not None else None
+        self._check(self.lib.dani_frontend_retain(self.h, sequence, frame, _fp(ku) if ku is not None else None,
+                                                  _ip(oc) if oc is not None else None, C.byref(g) if g is not None else None, C.byref(h)))
+        return h
+
+    def features_release(self, f):
+        self.lib.dani_features_release(f)
+
+    def features_count(self, f):
+        return self.lib.dani_features_count(f)
+
+    def features_fetch_grid(self, f, ncells, n):
+        offs = np.zeros(ncells + 1, np.int32); idx = np.zeros(max(n, 1), np.int32)
+        m = self.lib.dani_features_fetch_grid(f, _ip(offs), _ip(idx))
+        if m < 0:
+            raise DaniError(m, "dani_features_fetch_grid")
+        return offs, idx[:m].copy()
+
+    def desc_scan_resident(self, q_desc, train, cand_lists):
+        """desc_scan with the train descriptors / octaves of a retained frame (no descriptor upload)."""
+        q = np.ascontiguousarray(q_desc, np.float32).reshape(-1, 256)
+        nq = len(q)
+        offs = np.zeros(nq + 1, np.int32)
+        offs[1:] = np.cumsum([len(cl) for cl in cand_lists])
+        idx = np.ascontiguousarray(np.concatenate([np.asarray(cl, np.int32) for cl in cand_lists]) if offs[nq] else np.zeros(1, np.int32), np.int32)
+        bd = np.empty(nq, np.float32); bd2 = np.empty(nq, np.float32)
+        bi = np.empty(nq, np.int32); bl = np.empty(nq, np.int32); bl2 = np.empty(nq, np.int32)
+        cd = np.empty(max(int(offs[nq]), 1), np.float32)
+        self._check(self.lib.dani_desc_scan_resident(self.h, _fp(q), nq, train, _ip(offs), _ip(idx), _fp(bd), _fp(bd2), _ip(bi), _ip(bl), _ip(bl2), _fp(cd)))
+        return (bd, bd2, bi, bl, bl2), [cd[offs[i]:offs[i + 1]] for i in range(nq)]
+
+    def search_windows_resident(self, train, q_desc, qx, qy, qr, min_level=None, max_level=None, want_lists=True, cand_cap=1 << 20):
+        """Frame::GetFeaturesInArea + the best / second-best descriptor scan for nq map points on a retained frame, all on
+        the device.  Returns ((bestDist, bestDist2, bestIdx, bestLevel, bestLevel2), candidate lists, candidate distances)."""
+        q = np.ascontiguousarray(q_desc, np.float32).reshape(-1, 256)
+        nq = len(q)
+        qx = np.ascontiguousarray(qx, np.float32); qy = np.ascontiguousarray(qy, np.float32); qr = np.ascontiguousarray(qr, np.float32)
+        mn = np.ascontiguousarray(min_level, np.int32) if min_level is not None else None
+        mx = np.ascontiguousarray(max_level, np.int32) if max_level is not None else None
+        bd = np.empty(nq, np.float32); bd2 = np.empty(nq, np.float32)
+        bi = np.empty(nq, np.int32); bl = np.empty(nq, np.int32); bl2 = np.empty(nq, np.int32)
+        offs = np.zeros(nq + 1, np.int32)
+        ci = np.zeros(cand_cap if want_lists else 1, np.int32); cd = np.zeros(cand_cap if want_lists else 1, np.float32)
+        self._check(self.lib.dani_search_windows_resident(self.h, train, _fp(q), nq, _fp(qx), _fp(qy), _fp(qr), _ip(mn) if mn is not None else None,
+                                                          _ip(mx) if mx is not None else None, _fp(bd), _fp(bd2), _ip(bi), _ip(bl), _ip(bl2),
+                                                          _ip(offs), _ip(ci), _fp(cd), cand_cap if want_lists else 0))
+        lists = [ci[offs[i]:offs[i + 1]].copy() for i in range(nq)] if want_lists else None
+        dists = [cd[offs[i]:offs[i + 1]].copy() for i in range(nq)] if want_lists else None
+        return (bd, bd2, bi, bl, bl2), lists, dists
+
+    def bow_transform_resident(self, vocab, train, levelsup=4, weighting=0, norm=1):
+        n = self.features_count(train)
+        wid = np.zeros(max(n, 1), np.int32); wv = np.zeros(max(n, 1), np.float64); nw = C.c_int32(0)
+        fn = np.zeros(max(n, 1), np.int32); fo = np.zeros(n + 1, np.int32); ff = np.zeros(max(n, 1), np.int32); nf = C.c_int32(0)
+        self._check(self.lib.dani_bow_transform_resident(self.h, vocab, train, levelsup, weighting, norm, _ip(wid), wv.ctypes.data_as(C.POINTER(C.c_double)),
+                                                         C.byref(nw), _ip(fn), _ip(fo), _ip(ff), C.byref(nf)))
         bow = {int(wid[i]): float(wv[i]) for i in range(nw.value)}
         fv = {int(fn[i]): ff[fo[i]:fo[i + 1]].tolist() for i in range(nf.value)}
         return bow, fv

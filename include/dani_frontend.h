@@ -344,6 +344,49 @@ DANI_API int dani_bow_transform(dani_engine* e, dani_vocab* v, const float* feat
                                 int32_t norm, int32_t* word_ids, double* word_values, int32_t* n_words, int32_t* fv_node_ids,
                                 int32_t* fv_offsets, int32_t* fv_features, int32_t* n_fv_nodes);
 
+/* ---- device-resident consumers ("descriptors already resident on GPU after extraction") ------- */
+
+/* Frame's keypoint grid: FRAME_GRID_COLS x FRAME_GRID_ROWS (64 x 48, include/Frame.h:52-53) over the undistorted
+ * image bounds; inv_w = cols / (mnMaxX - mnMinX), inv_h = rows / (mnMaxY - mnMinY) as floats (src/Frame.cc:253-254). */
+typedef struct dani_grid { float min_x, min_y, inv_w, inv_h; int32_t cols, rows; } dani_grid;
+
+/* One frame's features kept in HBM for as long as the caller's Frame / KeyFrame object lives: what the reference holds as
+ * mvKeys(Un) + mDescriptors (include/Frame.h:236-250).  Nothing of it is re-uploaded by the calls below. */
+typedef struct dani_features dani_features;
+/* Keep frame `frame` of the LAST dani_frontend_batch call of `sequence` (device-to-device copy of keypoints, octaves and
+ * descriptors).  kpts_un: optional n x 2 HOST array of undistorted keypoints (Frame::UndistortKeyPoints, src/Frame.cc:749-782,
+ * dani_host_undistort_keypoints) used for the grid and the window tests instead of the extractor's coordinates (the
+ * reference's k1 == 0 calibrations copy them).  grid: optional; builds Frame::AssignFeaturesToGrid's lists on the device
+ * (src/Frame.cc:387-418).  octave: the n octaves as dani_sp_extract returned them (host; NULL = all 0). */
+DANI_API int dani_frontend_retain(dani_engine* e, int32_t sequence, int32_t frame, const float* kpts_un, const int32_t* octave,
+                                  const dani_grid* grid, dani_features** out);
+DANI_API void dani_features_release(dani_features* f);
+DANI_API int dani_features_count(const dani_features* f);
+/* Test hook: the device-built grid as CSR (cell = col * rows + row), as dani_host_assign_features_to_grid returns it. */
+DANI_API int dani_features_fetch_grid(dani_features* f, int32_t* cell_offsets, int32_t* cell_idx);
+
+/* dani_desc_scan with the train descriptors (and their octaves) taken from a retained frame: no descriptor upload. */
+DANI_API int dani_desc_scan_resident(dani_engine* e, const float* q_desc, int32_t nq, const dani_features* train,
+                                     const int32_t* cand_offsets, const int32_t* cand_idx, float* best_dist, float* best_dist2,
+                                     int32_t* best_idx, int32_t* best_level, int32_t* best_level2, float* cand_dist);
+
+/* The windowed search of LGmatcher::SearchByProjection in one call on a retained frame (needs its grid): for each of the nq
+ * map points, Frame::GetFeaturesInArea(qx, qy, qr, min_level, max_level) (src/Frame.cc:659-725; NULL level arrays = -1) builds
+ * the candidate list ON THE DEVICE, then the descriptor scan of dani_desc_best2 runs over it -- no candidate list and no
+ * train descriptor crosses PCIe.  Outputs as dani_desc_best2; optionally (cand_cap > 0) the lists themselves and every
+ * candidate's distance for callers that replay the sequential claim logic (cand_offsets [nq+1], cand_idx / cand_dist
+ * [cand_cap]; DANI_ERR_CAPACITY with cand_offsets[nq] = needed size when they do not fit). */
+DANI_API int dani_search_windows_resident(dani_engine* e, const dani_features* train, const float* q_desc, int32_t nq, const float* qx,
+                                          const float* qy, const float* qr, const int32_t* min_level, const int32_t* max_level,
+                                          float* best_dist, float* best_dist2, int32_t* best_idx, int32_t* best_level,
+                                          int32_t* best_level2, int32_t* cand_offsets, int32_t* cand_idx, float* cand_dist,
+                                          int32_t cand_cap);
+
+/* dani_bow_transform on a retained frame's descriptors (Frame::ComputeBoW, src/Frame.cc:740-747): no descriptor upload. */
+DANI_API int dani_bow_transform_resident(dani_engine* e, dani_vocab* v, const dani_features* f, int32_t levelsup, int32_t weighting,
+                                         int32_t norm, int32_t* word_ids, double* word_values, int32_t* n_words,
+                                         int32_t* fv_node_ids, int32_t* fv_offsets, int32_t* fv_features, int32_t* n_fv_nodes);
+
 /* ---- host logic exposed for CPU-side tests (no GPU needed) ---------------------------------- */
 
 /* The product's quadtree (DistributeOctTree, src/SPextractor.cpp:405-629) on host memory.
@@ -357,9 +400,6 @@ DANI_API int dani_host_cell_grid(int32_t width, int32_t height, int32_t* cells6,
 
 /* ---- feature hand-off formats (host, order-defining) ---------------- */
 
-/* Frame's keypoint grid: FRAME_GRID_COLS x FRAME_GRID_ROWS (64 x 48, include/Frame.h:52-53) over the undistorted
- * image bounds; inv_w = cols / (mnMaxX - mnMinX), inv_h = rows / (mnMaxY - mnMinY) as floats (src/Frame.cc:253-254). */
-typedef struct dani_grid { float min_x, min_y, inv_w, inv_h; int32_t cols, rows; } dani_grid;
 
 /* Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:387-418,727-737; monocular / RGB-D case): CSR over the cells in
  * mGrid[col][row] order (cell = col * rows + row): cell_offsets[cols*rows + 1], cell_idx[<= n] = keypoint indices in
