@@ -229,6 +229,8 @@ struct SpCall {
                                       // speculatively without boxes, while the YOLO chain is still running
   bool keep_desc_on_device = false;   // `desc` may be null: descriptors are consumed on the device (LightGlue)
   bool defer_desc_sync = false;       // descriptor read-back into pinned staging on stream2, no final synchronise
+  hipEvent_t wait_event = nullptr;    // the conv layers from index wait_layer on wait for this event (recorded on another stream)
+  int wait_layer = 1;
   int reserve_lds_bytes = 0;          // fused call with YOLO on the second stream: unused dynamic LDS added to the conv layers in
   unsigned reserve_lds_mask = 0;      // reserve_lds_mask (bit i = layer i), so that a CU keeps a free slot for YOLO's workgroups
   bool host_cull = false;             // single-level calls: candidate NMS + read-back are enqueued in phase 1, without the
@@ -238,6 +240,8 @@ struct YoloCall {
   Context* ctx = nullptr;
   bool alt_stream = false;            // run on the context's second (high-priority) stream, next to the SuperPoint network
   std::function<void(int, const float*, int)>* post = nullptr;   // per frame, inside the NMS worker: (frame, dets6, n)
+  std::function<void()>* mid_chain = nullptr;     // called once, after the first `mid_after` stages of the chain have been enqueued
+  int mid_after = 0;                              // (stage = model.0, model.1, C3 model.2, model.3, C3 model.4, ...)
   std::function<void()>* before_sync = nullptr;   // host work of the caller to run after the chain is enqueued, before waiting for it
 };
 struct LgCall {

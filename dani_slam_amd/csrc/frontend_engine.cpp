@@ -127,9 +127,17 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     static const unsigned pad_mask = getenv("DANI_SP_LDS_PAD_MASK") ? (unsigned)strtoul(getenv("DANI_SP_LDS_PAD_MASK"), nullptr, 0) : 0u;
     sp_call.reserve_lds_bytes = pad_kb * 1024; sp_call.reserve_lds_mask = pad_mask;
   }
-  int rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
+  // YOLO's first stages (190x320 / 95x160 resolution: its largest kernels) suffer most from sharing the chip with conv1b's
+  // 9600 workgroups, and the YOLO chain, not SuperPoint, is the critical path of this phase.  With head > 0 the chain's first
+  // `head` stages are enqueued first and SuperPoint's MFMA layers wait for them (conv1a, HBM-bound, does not).
+  static const int yolo_head = getenv("DANI_YOLO_HEAD") ? atoi(getenv("DANI_YOLO_HEAD")) : 0;
+  const bool head_first = p->use_yolo && yolo_head > 0 && yolo_head <= 7;
+  int rc = 0;
+  auto enqueue_sp_network = [&]() -> int {
+    return sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, nullptr, nullptr, p->lapping, kpts_xy, resp,
                            octave.data(), size.data(), desc, cap, n_out, mono_index);
-  if (rc) return rc;
+  };
+  if (!head_first && (rc = enqueue_sp_network())) return rc;
 
   // ---- 1. YOLO -> dynamic boxes (Tracking.cc:1535-1539)
   std::vector<int32_t> boxes, offs(B + 1, 0);
@@ -159,8 +167,17 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
                             octave.data(), size.data(), desc, cap, n_out, mono_index);
     };
     yolo_call.before_sync = &speculate;
+    int mid_rc = 0;
+    std::function<void()> mid = [&] {   // YOLO's head is enqueued: SuperPoint's network follows, its MFMA layers behind the head
+      (void)hipEventRecord(c->ev_y0, c->stream2);
+      sp_call.wait_event = c->ev_y0; sp_call.wait_layer = 1;
+      mid_rc = enqueue_sp_network();
+      sp_call.wait_event = nullptr;
+    };
+    if (head_first) { yolo_call.mid_chain = &mid; yolo_call.mid_after = yolo_head; }
     rc = yolo_detect_impl(e, yolo_call, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
     if (rc) return rc;
+    if (mid_rc) return mid_rc;
     for (int b = 0; b < B; b++) {
       const int k = kk[b];
       n_boxes[b] = k;

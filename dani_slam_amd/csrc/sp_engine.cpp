@@ -275,6 +275,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       if (lprof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
       const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
       for (int i = 1; i < 12; i++) {
+        if (call.wait_event && l == 0 && i == call.wait_layer) HIP_TRY(e, hipStreamWaitEvent(s, call.wait_event, 0));
         const int reserve = (call.reserve_lds_mask >> i) & 1 ? call.reserve_lds_bytes : 0;
         if (!launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, s, reserve)) {
           (void)hipStreamSynchronize(s);

@@ -248,18 +248,20 @@ void yolo_c3(const YoloWeights* W, YoloContext* Y, const C3Def& c3, YView x, YVi
   yolo_conv(W, p + ".cv3.conv", YView{&cat, 0, 2 * c_}, out, nullptr, B, s);
 }
 
-void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thresh, hipStream_t s) {
+void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thresh, hipStream_t s, const YoloCall* call = nullptr) {
   auto& b = Y->buf;
+  int stage = 0;
+  auto mark = [&] { if (call && call->mid_chain && ++stage == call->mid_after) (*call->mid_chain)(); };
   auto V = [&](const char* n) { const ActDesc& a = b.at(n); return YView{&a, 0, a.C}; };
   auto S = [&](const char* n, int c0, int C) { return YView{&b.at(n), c0, C}; };
   (void)hipMemsetAsync(Y->cand_count, 0, (size_t)B * 4, s);   // candidate counters of the decode at the end
-  yolo_conv(W, "model.0.conv", YView{&b.at("in"), 0, 4}, V("b0"), nullptr, B, s);
-  yolo_conv(W, "model.1.conv", V("b0"), V("b1"), nullptr, B, s);
-  yolo_c3(W, Y, kC3[0], V("b1"), V("b2"), B, s);
-  yolo_conv(W, "model.3.conv", V("b2"), V("b3"), nullptr, B, s);
-  yolo_c3(W, Y, kC3[1], V("b3"), S("cat16", 128, 128), B, s);            // x4 -> second half of cat16
-  yolo_conv(W, "model.5.conv", S("cat16", 128, 128), V("b5"), nullptr, B, s);
-  yolo_c3(W, Y, kC3[2], V("b5"), S("cat12", 256, 256), B, s);            // x6 -> second half of cat12
+  yolo_conv(W, "model.0.conv", YView{&b.at("in"), 0, 4}, V("b0"), nullptr, B, s); mark();
+  yolo_conv(W, "model.1.conv", V("b0"), V("b1"), nullptr, B, s); mark();
+  yolo_c3(W, Y, kC3[0], V("b1"), V("b2"), B, s); mark();
+  yolo_conv(W, "model.3.conv", V("b2"), V("b3"), nullptr, B, s); mark();
+  yolo_c3(W, Y, kC3[1], V("b3"), S("cat16", 128, 128), B, s); mark();            // x4 -> second half of cat16
+  yolo_conv(W, "model.5.conv", S("cat16", 128, 128), V("b5"), nullptr, B, s); mark();
+  yolo_c3(W, Y, kC3[2], V("b5"), S("cat12", 256, 256), B, s); mark();            // x6 -> second half of cat12
   yolo_conv(W, "model.7.conv", S("cat12", 256, 256), V("b7"), nullptr, B, s);
   yolo_c3(W, Y, kC3[3], V("b7"), V("b8"), B, s);
   // SPPF
@@ -334,7 +336,8 @@ int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, i
   HIP_TRY(e, hipEventRecord(c->ev_y0, s));
   launch_yolo_preproc(dimg, B, W, H, stride, fbytes, Y->buf.at("in"), s);
   t_yolo_launch_ok = true;
-  yolo_forward(Wt, Y, B, score_thresh, s);
+  yolo_forward(Wt, Y, B, score_thresh, s, &call);
+  if (call.mid_chain && (call.mid_after < 1 || call.mid_after > 7)) (*call.mid_chain)();   // never skip the caller's work
   if (!t_yolo_launch_ok) { (void)hipStreamSynchronize(s); return fail(e, DANI_ERR_UNSUPPORTED, "YOLO conv launch refused its tensor shape"); }
   HIP_TRY(e, hipEventRecord(c->ev_y1, s));
   HIP_TRY(e, hipGetLastError());
