@@ -179,62 +179,6 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// linear_sk_kernel: the same layer for SMALL token counts (one LightGlue pair, the per-node groups: a few thousand
-// tokens).  There the 64 x 64 tiles of linear_fm_kernel are fewer than the chip's CUs (T = 2050, OUT = 256: 132
-// workgroups for 256 CUs) and a launch lasts as long as ONE workgroup's serial walk over K: 16 us per launch, 0.9 ms of
-// a 3.4 ms stereo frame (profiles/r02_config3_kernel_stats.csv).  Here a workgroup owns ONE 32 x 32 output tile and its
-// four waves split K four ways -- straight from L2 into the MFMA operands (per k-pair one coalesced 128-B row segment of
-// the packed weights and one of X per lane half; no LDS staging, no barrier in the loop) -- then waves 1..3 hand their
-// partial tiles to wave 0 through LDS: acc = ((bias + p0) + p1) + p2) + p3, epilogue as linear_fm_kernel.
-// 4 x more workgroups, each a quarter as long.  The sum over K is formed in four segments instead of two interleaved
-// chains, so results differ from linear_fm_kernel in the last bits (LightGlue is tolerance-checked at 1e-3, not bit-exact).
-// Needs K0 % (K / 4) == 0 (each wave's K range lies in one source): K = 256 or 256 + 256 in LightGlue.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void linear_sk_kernel(LinArgs a) {
-  __shared__ float red[3][16][64];
-  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt32 = (a.T + 31) >> 5;
-  const int tile = blockIdx.x % nt32, o32 = blockIdx.x / nt32;
-  const int K = a.K0 + a.K1, kq = K >> 2, k0 = wave * kq;
-  const float* xs = (k0 < a.K0) ? a.x0 + (size_t)k0 * a.ld : a.x1 + (size_t)(k0 - a.K0) * a.ld;
-  const int tok = tile * 32 + j;                       // columns beyond T are padding inside ld: loaded, never stored
-  // packed weights [out tile of 64][k pair][k parity][64 outs] (pack_conv_weights with 1x1 taps): lane = (parity h, out j)
-  const float* wp = a.w + (size_t)(o32 >> 1) * K * LIN_NCO + (size_t)(k0 >> 1) * 128 + h * 64 + (o32 & 1) * 32 + j;
-  const float* xp = xs + (size_t)h * a.ld + tok;
-  f32x16 acc, acc2;
-#pragma unroll
-  for (int r = 0; r < 16; r++) { acc[r] = wave == 0 ? a.bias[o32 * 32 + acc_row(r, h)] : 0.0f; acc2[r] = 0.0f; }
-  const int npairs = kq >> 1;                          // 32 (K = 256) or 64 (K = 512)
-  constexpr int U = 16;                                // k-pairs per batch: 32 loads in flight per lane, then 16 MFMAs
-  for (int kp0 = 0; kp0 < npairs; kp0 += U) {
-    float av[U], bv[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) { av[u] = wp[(size_t)(kp0 + u) * 128]; bv[u] = xp[(size_t)(kp0 + u) * 2 * a.ld]; }
-#pragma unroll
-    for (int u = 0; u < U; u += 2) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u + 1], bv[u + 1], acc2, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; r++) acc[r] += acc2[r];
-  if (wave > 0) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) red[wave - 1][r][lane] = acc[r];
-  }
-  __syncthreads();
-  if (wave > 0) return;
-#pragma unroll
-  for (int w = 0; w < 3; w++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] += red[w][r][lane];
-  LinEpi ep;
-  ep.y = a.y; ep.res = a.res; ep.cosb = a.cosb; ep.sinb = a.sinb; ep.bias = nullptr; ep.ld = a.ld; ep.rot_rows = a.rot_rows; ep.alpha = a.alpha;
-  lin_epilogue<false>(acc, o32 * 32, h, tok, tok < a.T, ep);
-}
-
 int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = the 64-token tile)
 
 bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
@@ -249,12 +193,6 @@ bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   // 48 KB, 3 per CU) on every LightGlue shape from 16 k to 66 k tokens by 7-17 % (tools/probes/lin_bench.hip), so it is
   // always used; the larger instantiations stay reachable through the probe's tuning hook.
   auto grid = [&](int tt) { return dim3((unsigned)(((T + tt - 1) / tt + 7) / 8 * 8 * otiles)); };   // see the kernel: 8 XCDs
-  // small token counts: fewer 64 x 64 tiles than half a round of the chip's slots -> the split-K form (4 x the workgroups)
-  const int K = K0 + K1;
-  if ((g_lin_force_tt == 0 || g_lin_force_tt == 32) && ((T + 63) / 64) * otiles < 640 && K % 64 == 0 && K0 % (K / 4) == 0 && (K / 4) % 32 == 0) {
-    hipLaunchKernelGGL(linear_sk_kernel, dim3((unsigned)(((T + 31) / 32) * (OUT / 32))), dim3(256), 0, s, a);
-    return true;
-  }
   if (g_lin_force_tt == 256) hipLaunchKernelGGL(linear_fm_kernel<256>, grid(256), dim3(256), 0, s, a);
   else if (g_lin_force_tt == 128) hipLaunchKernelGGL(linear_fm_kernel<128>, grid(128), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(linear_fm_kernel<64>, grid(64), dim3(256), 0, s, a);
