@@ -132,7 +132,7 @@ int dani_engine_create(const dani_config* cfg, dani_engine** out) {
   for (int i = 0; i < e->cfg.n_contexts; i++) {
     Context* c = new Context();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        create_priority_stream(&c->stream2) != hipSuccess || hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
+        create_priority_stream(&c->stream2) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
     (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
     (void)hipEventCreate(&c->ev_lg0); (void)hipEventCreate(&c->ev_lg1);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
@@ -149,7 +149,6 @@ void dani_engine_destroy(dani_engine* e) {
   for (Context* c : e->ctxs) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
   }
   lg_release(e); yolo_release(e); seq_release(e);
   for (Context* c : e->ctxs) {
@@ -160,7 +159,6 @@ void dani_engine_destroy(dani_engine* e) {
     if (c->scan_ws) (void)hipFree(c->scan_ws);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     delete c;
   }
   for (void* p : e->weight_allocs) (void)hipFree(p);

@@ -32,7 +32,6 @@ constexpr int CAND_FAST = 4096;  // candidates per frame read back together with
 struct Context {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // YOLO (concurrent with the SuperPoint conv stack) and overlapped D2H copies
-  hipStream_t stream3 = nullptr;   // LightGlue's tail-tile launches next to the main launches (lg_forward)
   hipEvent_t ev_desc = nullptr, ev_y0 = nullptr, ev_y1 = nullptr, ev_lg0 = nullptr, ev_lg1 = nullptr;
   int W = 0, H = 0, B = 0;  // shapes the buffers are built for
   int nlevels = 0;

@@ -101,7 +101,6 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     Context* c = new Context();
     HIP_TRY(e, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(e, create_priority_stream(&c->stream2));
-    HIP_TRY(e, hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
     (void)hipEventCreate(&c->ev_lg0); (void)hipEventCreate(&c->ev_lg1);
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);

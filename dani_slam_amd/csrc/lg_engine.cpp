@@ -43,8 +43,6 @@ struct LgContext {
   // profiling of the attention kernel (dominant kernel of the full front-end): events around its 18 launches
   hipEvent_t aev[36] = {};
   hipEvent_t lnev[2 * LG_LINEARS] = {};   // around every linear_fm launch of a forward pass
-  hipEvent_t tev[2 * LG_LINEARS] = {};    // fork / join events of the tail-tile launches on the second stream (lg_forward)
-  bool tev_ready = false;
   bool aev_ready = false;
   float attn_ms = 0.0f, lin_ms = 0.0f;
   double attn_flops = 0.0, lin_flops = 0.0;
@@ -65,7 +63,6 @@ void lg_release(dani_engine* e) {
     for (void* p : L->dev_allocs) (void)hipFree(p);
     for (void* p : L->host_allocs) (void)hipHostFree(p);
     if (L->aev_ready) { for (auto& ev : L->aev) (void)hipEventDestroy(ev); for (auto& ev : L->lnev) (void)hipEventDestroy(ev); }
-    if (L->tev_ready) for (auto& ev : L->tev) (void)hipEventDestroy(ev);
     delete L;
     c->lg = nullptr;
   }
@@ -249,10 +246,10 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
 }
 
 // the 9-layer forward + assignment statistics on stream s; the sets in L->d_sets point at their token-major inputs
-struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T, T_main; };   // T = all main regions (T_main) + the tail region
+struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T; };   // T = all main regions + the tail region
 
 // false: a linear layer refused its shape (nothing of that layer was launched)
-bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, hipStream_t s2, bool prof, int gemm) {
+bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof, int gemm) {
   const int ld = L->ld, nsets = sh.nsets, max_n = sh.max_n, T = sh.T, max_np = round_up(max_n, 32);
   if (prof && !L->aev_ready) {
     for (auto& ev : L->aev) (void)hipEventCreate(&ev);
@@ -268,33 +265,11 @@ bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
   launch_desc_to_fm(L->d_sets, nsets, sh.max_span, L->x, ld, s);
   launch_posenc(L->d_sets, nsets, sh.max_span, W->wr, L->cosb, L->sinb, ld, s);
   bool ok = true;
-  // The shared tail region (the quadtree's 1-2 keypoints of overshoot per set) is a 257th token tile behind 256 full ones at
-  // the bench shape: 1028 workgroups for 1024 four-per-CU slots, so a few CUs carry five and the launch ends 5-18 % later
-  // (tools/probes/lin_bench.hip: ffn.3 42.7 -> 50.6 us, ffn.0 74.2 -> 78.8, qk|v 41.1 -> 43.4 at 16384 vs 16416 tokens).
-  // When the main regions fill whole 64-token tiles, the tail tile is launched on its own, on the context's second stream,
-  // next to the main launch: fork after everything enqueued so far, join before the next consumer.  Same kernel, same
-  // arithmetic per token (a token's result does not depend on which launch computes it).
-  const int Tm = sh.T_main;
-  const bool split_tail = s2 && Tm >= 64 * 64 && Tm % 64 == 0 && T > Tm && T - Tm <= 64 && !getenv("DANI_LG_NO_TAIL_SPLIT");
-  if (split_tail && !L->tev_ready) { for (auto& ev : L->tev) (void)hipEventCreate(&ev); L->tev_ready = true; }
-  int ti = 0;
-  auto launch = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha,
-                    int c0, int ntok, hipStream_t st) {
-    const float* xx1 = x1 ? x1 + c0 : nullptr;
-    const float* rr = res ? res + c0 : nullptr;
-    if (gemm != DANI_LG_GEMM_F32) return launch_linear_x3(x0 + c0, K0, xx1, K1, l.w3, l.b, y + c0, l.out, ntok, ld, rr, L->cosb + c0, L->sinb + c0, rot, alpha, st);
-    return launch_linear_fm(x0 + c0, K0, xx1, K1, l.w, l.b, y + c0, l.out, ntok, ld, rr, L->cosb + c0, L->sinb + c0, rot, alpha, st);
-  };
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
-    if (split_tail) { (void)hipEventRecord(L->tev[ti], s); (void)hipStreamWaitEvent(s2, L->tev[ti], 0); }
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
-    ok = launch(l, x0, K0, x1, K1, y, res, rot, alpha, 0, split_tail ? Tm : T, s) && ok;
+    if (gemm != DANI_LG_GEMM_F32) ok = launch_linear_x3(x0, K0, x1, K1, l.w3, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s) && ok;
+    else ok = launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s) && ok;
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
-    if (split_tail) {
-      ok = launch(l, x0, K0, x1, K1, y, res, rot, alpha, Tm, T - Tm, s2) && ok;
-      (void)hipEventRecord(L->tev[ti + 1], s2); (void)hipStreamWaitEvent(s, L->tev[ti + 1], 0);
-      ti += 2;
-    }
   };
   for (int i = 0; i < LG_LAYERS; i++) {
     const LgBlockW& S = W->self_[i]; const LgBlockW& C = W->cross_[i];
@@ -394,7 +369,7 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
     b.partner_off = a.tok_off; b.partner_n = a.n; b.partner_nmain = a.nmain; b.partner_tail_off = a.tail_off;
   }
   const int T = T_main + round_up(ntail, 32);
-  sh.max_n = max_n; sh.T = T; sh.T_main = T_main;
+  sh.max_n = max_n; sh.T = T;
   // sizes: explicit (w,h) or 1 + max - min of the keypoints (needs host keypoints)
   std::vector<float> hk;
   auto host_kpts = [&](const float* k, int p, int n) -> const float* {
@@ -437,7 +412,7 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
   HIP_TRY(e, hipMemcpyAsync(L->d_sets, L->h_sets, sizeof(LgSet) * 2 * P, hipMemcpyHostToDevice, s));
   HIP_TRY(e, hipEventRecord(c->ev_lg0, s));
   const bool prof = e->profiling;
-  if (max_n > 0 && !lg_forward(W, L, sh, s, c->stream3, prof, e->lg_gemm)) {
+  if (max_n > 0 && !lg_forward(W, L, sh, s, prof, e->lg_gemm)) {
     (void)hipStreamSynchronize(s);
     return fail(e, DANI_ERR_UNSUPPORTED, "LightGlue batch of %d token columns exceeds the linear kernels' addressing range", L->ld);
   }
