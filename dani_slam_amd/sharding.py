@@ -81,4 +81,8 @@ def exchange_boundary_features(eng, last_frame: int, cap: int, device=None, sequ
         return mine.reshape(1, nfl)
     out = torch.empty(world * nfl, dtype=torch.float32, device=mine.device)
     dist.all_gather_into_tensor(out, mine)
+    if on_gpu:
+        # the collective is only ENQUEUED on torch's stream when the call returns; the engine reads the slab from its own
+        # (non-blocking) HIP stream, so the gathered bytes must have landed before the pointer is handed over
+        torch.cuda.current_stream(mine.device).synchronize()
     return out.reshape(world, nfl)
