@@ -228,57 +228,40 @@ __device__ __forceinline__ float lg_erff(float a) {
   return t > 0.927734375f ? r : q;
 }
 
-// Round 2: 16-byte accesses.  A lane owns 4 consecutive tokens (lane & 15) of one of 4 feature rows (lane >> 4); wave g
-// walks its 32 features in 8 steps of 4 rows, so every load / store is a dwordx4 and a wave instruction moves four 256-B
-// row segments instead of one (the dword form reached 3.2 TB/s on 67 MB; guide: "vectorize memory access -- always").
-// Statistics: per-lane float4 partial sums over its 8 rows, the 4 row lanes combined with two shuffles, the 16 waves
-// through LDS -- two-pass (mean, then centred squares) as before.
 __global__ __launch_bounds__(1024) void ln_gelu_kernel(float* hbuf, const float* gamma, const float* beta, int T, int ld) {
   __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, q = lane & 15, r = lane >> 4;
-  const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bases on the scalar unit
-  const int tok = blockIdx.x * 64 + 4 * q;                          // T is padded inside ld: whole float4s are addressable
-  f32x4 v[8];
-  f32x4 s4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int lp = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bases on the scalar unit
+  const int tok = blockIdx.x * 64 + lp;
+  const bool ok = tok < T;
+  float v[32];
+  float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    v[i] = *reinterpret_cast<const f32x4*>(hbuf + (size_t)(g * 32 + 4 * i + r) * ld + tok);
-    s4 += v[i];
+  for (int i = 0; i < 32; i++) {
+    v[i] = ok ? (hbuf + (size_t)(g * 32 + i) * ld)[tok] : 0.0f;
+    s += v[i];
   }
-#pragma unroll
-  for (int c = 0; c < 4; c++) { s4[c] += __shfl_xor(s4[c], 16); s4[c] += __shfl_xor(s4[c], 32); }
-  if (r == 0) *reinterpret_cast<f32x4*>(&red[g][4 * q]) = s4;
+  red[g][lp] = s;
   __syncthreads();
-  f32x4 tot = {0.0f, 0.0f, 0.0f, 0.0f};
+  float tot = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 16; k++) tot += *reinterpret_cast<const f32x4*>(&red[k][4 * q]);
-  const f32x4 mean = tot * (1.0f / 512.0f);
+  for (int k = 0; k < 16; k++) tot += red[k][lp];
+  const float mean = tot * (1.0f / 512.0f);
   __syncthreads();
-  f32x4 q4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  float s2 = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { const f32x4 d = v[i] - mean; q4 += d * d; }
-#pragma unroll
-  for (int c = 0; c < 4; c++) { q4[c] += __shfl_xor(q4[c], 16); q4[c] += __shfl_xor(q4[c], 32); }
-  if (r == 0) *reinterpret_cast<f32x4*>(&red[g][4 * q]) = q4;
+  for (int i = 0; i < 32; i++) { const float d = v[i] - mean; s2 += d * d; }
+  red[g][lp] = s2;
   __syncthreads();
-  f32x4 tv = {0.0f, 0.0f, 0.0f, 0.0f};
+  float tv = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 16; k++) tv += *reinterpret_cast<const f32x4*>(&red[k][4 * q]);
-  f32x4 rstd;
+  for (int k = 0; k < 16; k++) tv += red[k][lp];
+  const float rstd = 1.0f / sqrtf(tv * (1.0f / 512.0f) + 1e-5f);
+  if (!ok) return;
 #pragma unroll
-  for (int c = 0; c < 4; c++) rstd[c] = 1.0f / sqrtf(tv[c] * (1.0f / 512.0f) + 1e-5f);
-  if (tok >= T) return;      // whole quads of padding columns (T is a multiple of 32)
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int f = g * 32 + 4 * i + r;
-    const float ga = gamma[f], be = beta[f];
-    f32x4 o;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const float y = (v[i][c] - mean[c]) * rstd[c] * ga + be;
-      o[c] = 0.5f * y * (1.0f + lg_erff(y * 0.70710678118654752440f));
-    }
-    *reinterpret_cast<f32x4*>(hbuf + (size_t)f * ld + tok) = o;
+  for (int i = 0; i < 32; i++) {
+    const int f = g * 32 + i;
+    const float y = (v[i] - mean) * rstd * gamma[f] + beta[f];
+    (hbuf + (size_t)f * ld)[tok] = 0.5f * y * (1.0f + lg_erff(y * 0.70710678118654752440f));
   }
 }
 
