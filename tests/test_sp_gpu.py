@@ -217,3 +217,29 @@ def test_other_image_sizes(sp_weights, w, h):
     r = e.sp_extract_batch(img[None], nfeatures=1500)[0]
     assert np.array_equal(r["kpts"], ref["kpts"]) and np.array_equal(r["desc"], ref["desc"])
     e.close()
+
+
+def test_more_callers_than_contexts_wait_instead_of_failing(sp_weights):
+    """Four host threads on an engine with two contexts (the reference runs two extractors concurrently,
+    src/Frame.cc:124-127, and its mapping threads construct matchers next to Tracking): a call that finds every context
+    taken waits for one, it no longer fails with 'all contexts busy'; every thread gets the single-threaded result."""
+    import threading
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=1, n_contexts=2, weights=sp_weights)
+    imgs = [synth.frame(i) for i in range(4)]
+    want = [e.sp_extract_batch(im[None])[0] for im in imgs]
+    got, errs = [None] * 4, []
+
+    def worker(i):
+        try:
+            for _ in range(6):
+                got[i] = e.sp_extract_batch(imgs[i][None])[0]
+        except Exception as ex:        # surfaces in the main thread below
+            errs.append(ex)
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for a, b in zip(got, want):
+        assert np.array_equal(a["kpts"], b["kpts"]) and np.array_equal(a["desc"], b["desc"])
+    e.close()
