@@ -129,6 +129,7 @@ void launch_desc_best2(const float* q, const float* t, const int32_t* t_level, c
 // SURVEY 8(f) rank 2 on the device (handoff_kernels.hip)
 void launch_grid_assign(const float* kxy, int n, float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
                         int32_t* cell_of, int32_t* cell_offsets, int32_t* cell_idx, hipStream_t s);
+void launch_undistort(const float* xy, int n, const float K4[4], const float* dist, int ndist, float* out, hipStream_t s);
 void launch_area_count(const float* kxy, const int32_t* octave, float min_x, float min_y, float inv_w, float inv_h, int cols, int rows,
                        const int32_t* cell_offsets, const int32_t* cell_idx, const float* qx, const float* qy, const float* qr,
                        const int32_t* min_level, const int32_t* max_level, int nq, int32_t* counts, int32_t* cand_offsets, hipStream_t s);

@@ -619,6 +619,45 @@ int dani_frontend_retain(dani_engine* e, int32_t sequence, int32_t frame, const 
   return DANI_OK;
 }
 
+int dani_features_undistort(dani_engine* e, dani_features* f, const float* K4, const float* dist, int32_t ndist, const dani_grid* grid,
+                            float* kpts_un_out) {
+  if (!e) return DANI_ERR_INVALID;
+  if (!f || f->e != e || !K4 || ndist < 0 || ndist > 5 || (ndist && !dist) || !(K4[0] != 0.0f) || !(K4[1] != 0.0f) ||
+      (grid && (grid->cols < 1 || grid->rows < 1 || (int64_t)grid->cols * grid->rows > (1 << 20))))
+    return fail(e, DANI_ERR_INVALID, "bad dani_features_undistort argument");
+  HIP_TRY(e, hipSetDevice(e->device));
+  std::lock_guard<std::mutex> lk(f->mu);
+  CtxLease lease(e, nullptr);
+  hipStream_t s = lease.c->stream;
+  const int n = f->n, m = std::max(n, 1);
+  if (n && ndist >= 1 && dist[0] != 0.0f) {
+    float* tmp = nullptr;
+    HIP_TRY(e, hipMalloc((void**)&tmp, (size_t)m * 8));
+    launch_undistort(f->d_kxy, n, K4, dist, ndist, tmp, s);
+    hipError_t st = hipStreamSynchronize(s);
+    if (st == hipSuccess) st = hipGetLastError();
+    if (st != hipSuccess) { (void)hipFree(tmp); return fail(e, DANI_ERR_HIP, "undistort kernel failed: %s", hipGetErrorString(st)); }
+    (void)hipFree(f->d_kxy);
+    f->d_kxy = tmp;
+  }
+  if (grid) {
+    const int ncells = grid->cols * grid->rows;
+    for (void* p : {(void*)f->d_cell_offsets, (void*)f->d_cell_idx}) if (p) (void)hipFree(p);
+    f->d_cell_offsets = nullptr; f->d_cell_idx = nullptr; f->has_grid = false;
+    int32_t* cell_of = nullptr;
+    HIP_TRY(e, hipMalloc((void**)&f->d_cell_offsets, (size_t)(ncells + 1) * 4));
+    HIP_TRY(e, hipMalloc((void**)&f->d_cell_idx, (size_t)m * 4));
+    HIP_TRY(e, hipMalloc((void**)&cell_of, (size_t)m * 4));
+    launch_grid_assign(f->d_kxy, n, grid->min_x, grid->min_y, grid->inv_w, grid->inv_h, grid->cols, grid->rows, cell_of, f->d_cell_offsets, f->d_cell_idx, s);
+    const hipError_t st = hipStreamSynchronize(s);
+    (void)hipFree(cell_of);
+    if (st != hipSuccess || hipGetLastError() != hipSuccess) return fail(e, DANI_ERR_HIP, "grid kernel failed");
+    f->grid = *grid; f->has_grid = true;
+  }
+  if (kpts_un_out && n) HIP_TRY(e, hipMemcpy(kpts_un_out, f->d_kxy, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return DANI_OK;
+}
+
 int dani_features_fetch_grid(dani_features* f, int32_t* cell_offsets, int32_t* cell_idx) {
   if (!f || !f->has_grid || !cell_offsets) return DANI_ERR_INVALID;
   (void)hipSetDevice(f->e->device);

@@ -53,6 +53,37 @@ void launch_grid_assign(const float* kxy, int n, float min_x, float min_y, float
                      cell_offsets, cell_idx);
 }
 
+// Frame::UndistortKeyPoints (src/Frame.cc:749-782) = cv::undistortPoints(pts, pts, K, distCoef, noArray(), K): the five
+// fixed-point iterations of OpenCV's calib3d in double precision, operation for operation as undistort_keypoints in
+// host_logic.cpp (IEEE double add / multiply / divide, no contraction: -ffp-contract=off), so the two agree bit for bit.
+struct UndistortArgs { double fx, fy, cx, cy, k[5]; };
+__global__ void undistort_kernel(const float* xy, int n, UndistortArgs a, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double ifx = 1.0 / a.fx, ify = 1.0 / a.fy;
+  double x = ((double)xy[2 * i] - a.cx) * ifx, y = ((double)xy[2 * i + 1] - a.cy) * ify;
+  const double x0 = x, y0 = y;
+  for (int it = 0; it < 5; it++) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1.0 / (1.0 + ((a.k[4] * r2 + a.k[1]) * r2 + a.k[0]) * r2);
+    if (icdist < 0) { x = x0; y = y0; break; }
+    const double dx = 2 * a.k[2] * x * y + a.k[3] * (r2 + 2 * x * x);
+    const double dy = a.k[2] * (r2 + 2 * y * y) + 2 * a.k[3] * x * y;
+    x = (x0 - dx) * icdist;
+    y = (y0 - dy) * icdist;
+  }
+  const double xx = a.fx * x + a.cx, yy = a.fy * y + a.cy;
+  out[2 * i] = (float)xx;
+  out[2 * i + 1] = (float)yy;
+}
+void launch_undistort(const float* xy, int n, const float K4[4], const float* dist, int ndist, float* out, hipStream_t s) {
+  if (n <= 0) return;
+  UndistortArgs a;
+  a.fx = K4[0]; a.fy = K4[1]; a.cx = K4[2]; a.cy = K4[3];
+  for (int i = 0; i < 5; i++) a.k[i] = i < ndist ? (double)dist[i] : 0.0;
+  hipLaunchKernelGGL(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, s, xy, n, a, out);
+}
+
 // GetFeaturesInArea for nq windows: one wavefront per window.  FILL = false counts (counts[q]); FILL = true writes the
 // candidate indices at cand_offsets[q] in the reference's order.  The arithmetic mirrors features_in_area (host_logic.cpp).
 template <bool FILL>

@@ -86,6 +86,7 @@ def load_library():
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_retain.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, _i32, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.dani_features_undistort.argtypes = [C.c_void_p, C.c_void_p, _f, _f, C.c_int32, C.c_void_p, _f]
     lib.dani_features_release.argtypes = [C.c_void_p]
     lib.dani_features_release.restype = None
     lib.dani_features_count.argtypes = [C.c_void_p]
@@ -620,6 +621,15 @@ class Engine:
         self._check(self.lib.dani_frontend_retain(self.h, sequence, frame, _fp(ku) if ku is not None else None,
                                                   _ip(oc) if oc is not None else None, C.byref(g) if g is not None else None, C.byref(h)))
         return h
+
+    def features_undistort(self, f, K4, dist, grid=None):
+        """Frame::UndistortKeyPoints on the retained coordinates, on the device; returns mvKeysUn [n, 2] (host copy)."""
+        K = np.ascontiguousarray(K4, np.float32); d = np.ascontiguousarray(dist, np.float32)
+        n = self.features_count(f)
+        out = np.zeros((max(n, 1), 2), np.float32)
+        g = _Grid(*grid) if grid is not None else None
+        self._check(self.lib.dani_features_undistort(self.h, f, _fp(K), _fp(d) if len(d) else None, len(d), C.byref(g) if g is not None else None, _fp(out)))
+        return out[:n]
 
     def features_release(self, f):
         self.lib.dani_features_release(f)

@@ -360,6 +360,12 @@ typedef struct dani_features dani_features;
  * (src/Frame.cc:387-418).  octave: the n octaves as dani_sp_extract returned them (host; NULL = all 0). */
 DANI_API int dani_frontend_retain(dani_engine* e, int32_t sequence, int32_t frame, const float* kpts_un, const int32_t* octave,
                                   const dani_grid* grid, dani_features** out);
+/* Frame::UndistortKeyPoints (src/Frame.cc:749-782) on the retained coordinates, on the device: mvKeysUn replaces the
+ * coordinates the grid and the window tests use (dist[0] == 0 or ndist == 0: unchanged, as the reference copies them);
+ * same arithmetic as dani_host_undistort_keypoints, bit for bit.  grid (optional) is (re)built from the new coordinates;
+ * kpts_un_out (optional, host, n x 2) receives mvKeysUn. */
+DANI_API int dani_features_undistort(dani_engine* e, dani_features* f, const float* K4, const float* dist, int32_t ndist,
+                                     const dani_grid* grid, float* kpts_un_out);
 DANI_API void dani_features_release(dani_features* f);
 DANI_API int dani_features_count(const dani_features* f);
 /* Test hook: the device-built grid as CSR (cell = col * rows + row), as dani_host_assign_features_to_grid returns it. */

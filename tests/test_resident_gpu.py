@@ -59,6 +59,27 @@ def test_grid_built_on_the_device(state):
     e.features_release(f)
 
 
+def test_undistort_on_the_device_equals_the_host_function(state):
+    """Frame::UndistortKeyPoints (src/Frame.cc:749-782) on the retained coordinates: bit-identical to
+    dani_host_undistort_keypoints (five fixed-point iterations in double), the grid rebuilt from mvKeysUn; the k1 == 0
+    calibration copies, as the reference does."""
+    from dani_slam_amd import frontend
+    e, out = state
+    K4 = (517.3, 516.5, 318.6, 255.3); dist = (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)      # TUM1-like
+    f = e.frontend_retain(0, octave=out[0]["octave"])
+    un = e.features_undistort(f, K4, dist, grid=GRID)
+    ref = frontend.host_undistort_keypoints(out[0]["kpts"], K4, dist)
+    assert np.array_equal(un, ref) and np.abs(un - out[0]["kpts"]).max() > 1.0
+    offs, idx = e.features_fetch_grid(f, 64 * 48, len(un))
+    ro, ri = _csr(ho.assign_features_to_grid(ref, *GRID[:4], 64, 48))
+    assert np.array_equal(offs, ro) and np.array_equal(idx, ri)
+    e.features_release(f)
+    f = e.frontend_retain(0)
+    assert np.array_equal(e.features_undistort(f, K4, (0.0, 0.3, 0.0, 0.0)), out[0]["kpts"])     # k1 == 0: copied
+    assert np.array_equal(e.features_undistort(f, K4, dist[:4]), frontend.host_undistort_keypoints(out[0]["kpts"], K4, dist[:4]))
+    e.features_release(f)
+
+
 def test_window_search_and_scan_on_resident_features(state):
     """Map points projected into frame 1: windows around (perturbed) keypoints of frame 0's scene, radii as
     SearchByProjection computes them, level ranges as its predicted-octave test (src/LGmatcher.cpp:60-82)."""
