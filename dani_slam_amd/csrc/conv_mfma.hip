@@ -38,6 +38,7 @@ struct ConvArgs {
   int iHp, iWp, ipady, oHp, oWp, opady;
   size_t in_fs, out_fs, res_fs;   // per-frame strides in floats (tensors may be channel slices of concat buffers)
   int tiles_x, tiles_y, cout_tiles, nchunks;
+  int ntiles, tiles_per_xcd;   // pixel tiles of the launch (B * tiles_y * tiles_x) and ceil(ntiles / 8)
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
@@ -76,11 +77,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, h = lane >> 5;
 
-  int bid = blockIdx.x;
-  const int ct = bid % a.cout_tiles; bid /= a.cout_tiles;
-  const int tx = bid % a.tiles_x; bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int b = bid / a.tiles_y;
+  // XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  In plain
+  // order (cout tile fastest) the 2-16 workgroups that read the SAME input tile land on different XCDs and every L2 fetches
+  // it again from the fabric: 122 MB per launch for YOLO's 1x1 layers against 16-31 MB algorithmic, 886 MB against 360 MB
+  // for the pooled SuperPoint layers, whose neighbouring tiles' halo rows were spread the same way
+  // (profiles/r02_pmc_summary.json).  Here XCD x owns a CONTIGUOUS range of pixel tiles and walks it in order, all cout
+  // tiles of a pixel tile back to back: slot = id / 8 counts (pixel tile, cout tile) pairs inside the XCD.  Speed only.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = slot % a.cout_tiles;
+  const int tl = slot / a.cout_tiles;
+  int tile = xcd * a.tiles_per_xcd + tl;
+  if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;      // padding of the grid (whole workgroup, before any barrier)
+  const int tx = tile % a.tiles_x; tile /= a.tiles_x;
+  const int ty = tile % a.tiles_y;
+  const int b = tile / a.tiles_y;
   const int y0 = ty * C::TH, x0 = tx * C::TW;
 
   const size_t iplane = (size_t)a.iHp * a.iWp;
@@ -247,7 +257,10 @@ static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   a.nchunks = L.CinPad / C::CC;
   // 32-bit byte offsets inside a frame (epilogue): refused, not launched; the engine reports DANI_ERR_UNSUPPORTED
   if ((size_t)(L.cout_tiles * C::NCO + 8) * io.oHp * io.oWp >= ((size_t)1 << 30)) return false;
-  const int grid = B * a.tiles_x * a.tiles_y * a.cout_tiles;
+  a.ntiles = B * a.tiles_x * a.tiles_y;
+  a.tiles_per_xcd = (a.ntiles + 7) / 8;
+  if (a.ntiles <= 0 || a.cout_tiles <= 0) return false;
+  const int grid = 8 * a.tiles_per_xcd * a.cout_tiles;      // 8 XCDs x (pixel tiles of one XCD) x cout tiles, see the kernel
   // reserve_lds: dynamic LDS the kernel never touches.  It only lowers how many of THESE workgroups fit on a CU, so that
   // a slot (registers, waves and the rest of the LDS) stays free for the workgroups of a concurrent stream (the fused
   // front-end: YOLO's chain of small dependent kernels next to SuperPoint's huge ones, sp_engine.cpp).
