@@ -45,6 +45,9 @@ enum ConvVariant {
   CONV3_BLK16S_RELU = 11, CONV1_BLK16S_LINEAR = 12, CONV3_BLK16S_SILU = 13, CONV3S2_BLK16S_SILU = 14, CONV1_BLK16S_SILU = 15,
   // narrow variants (32 couts per workgroup) of the 8x32-tile kernels, for layers with <= 32 output channels
   CONV6S2_ROW32N_SILU = 16, CONV3_ROW32N_SILU = 17, CONV1_ROW32N_SILU = 18,
+  // 4 x 32-pixel x 32-cout workgroups (one image row per wave) for the 12 x 20 level of YOLOv5s: three tiles cover a
+  // frame's 240 pixels at 62 % (the 8 x 16 tiles need four, 47 %)
+  CONV3_R4_SILU = 19, CONV3S2_R4_SILU = 20, CONV1_R4_SILU = 21, CONV1_R4_LINEAR = 22,
 };
 
 // tensor views for one conv launch: tensors may be channel slices of larger (concat) buffers
@@ -71,7 +74,7 @@ void pack_conv_weights(const float* w_oihw, const float* bias, int Cin, int Cout
                        float* w_packed, float* bias_packed);
 inline int conv_variant_cc(ConvVariant v) {
   return (v == CONV1_BLK16_LINEAR || v == CONV1_ROW32_SILU || v == CONV1_BLK16_SILU || v == CONV1_BLK16S_LINEAR ||
-          v == CONV1_BLK16S_SILU || v == CONV1_ROW32N_SILU) ? 32 : ((v == CONV6S2_ROW32_SILU || v == CONV6S2_ROW32N_SILU) ? 4 : 8);
+          v == CONV1_BLK16S_SILU || v == CONV1_ROW32N_SILU || v == CONV1_R4_SILU || v == CONV1_R4_LINEAR) ? 32 : ((v == CONV6S2_ROW32_SILU || v == CONV6S2_ROW32N_SILU) ? 4 : 8);
 }
 inline int conv_variant_nco(ConvVariant v) { return v >= CONV3_BLK16S_RELU ? 32 : 64; }   // couts per workgroup
 // the small-grid twin of a 16x16-tile variant (or the variant itself)

@@ -243,6 +243,11 @@ using CfgConv1Blk16sSilu = Cfg<1, 1, 2, 16, 1, 32, ACT_SILU, false, 1>;
 using CfgStem6Row32n     = Cfg<6, 2, 1, 32, 2, 4, ACT_SILU, false, 1>;
 using CfgRow32nSilu      = Cfg<3, 1, 1, 32, 2, 8, ACT_SILU, false, 1>;
 using CfgConv1Row32nSilu = Cfg<1, 1, 1, 32, 2, 32, ACT_SILU, false, 1>;
+// 4 x 32-pixel tiles (wave = one image row of 32 pixels, one accumulator) x 32 couts: the 12 x 20 level of YOLOv5s
+using CfgR4Silu          = Cfg<3, 1, 1, 32, 1, 8, ACT_SILU, false, 1>;
+using CfgS2R4Silu        = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1>;
+using CfgConv1R4Silu     = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1>;
+using CfgConv1R4         = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1>;
 
 template <class C>
 static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds) {
@@ -289,6 +294,10 @@ bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV6S2_ROW32N_SILU: return launch_cfg<CfgStem6Row32n>(L, io, B, s, reserve_lds);
     case CONV3_ROW32N_SILU: return launch_cfg<CfgRow32nSilu>(L, io, B, s, reserve_lds);
     case CONV1_ROW32N_SILU: return launch_cfg<CfgConv1Row32nSilu>(L, io, B, s, reserve_lds);
+    case CONV3_R4_SILU: return launch_cfg<CfgR4Silu>(L, io, B, s, reserve_lds);
+    case CONV3S2_R4_SILU: return launch_cfg<CfgS2R4Silu>(L, io, B, s, reserve_lds);
+    case CONV1_R4_SILU: return launch_cfg<CfgConv1R4Silu>(L, io, B, s, reserve_lds);
+    case CONV1_R4_LINEAR: return launch_cfg<CfgConv1R4>(L, io, B, s, reserve_lds);
   }
   return false;
 }

@@ -108,6 +108,11 @@ int yolo_pack_raw(dani_engine* e, YoloWeights* W, const std::string& name, const
     const int tiles = ((kYH[scale] + 15) / 16) * ((kYW[scale] + 15) / 16);
     if (e->cfg.max_batch * tiles * ((cout + 63) / 64) < 768) L.variant = conv_small_variant(L.variant);
   }
+  if (scale == 4 && !getenv("DANI_YOLO_NO_R4")) {   // 12 x 20: 4 x 32-pixel tiles waste less of every MFMA on padding pixels
+    if (k == 3 && s == 2) L.variant = CONV3S2_R4_SILU;
+    else if (k == 3) L.variant = CONV3_R4_SILU;
+    else if (k == 1) L.variant = act ? CONV1_R4_SILU : CONV1_R4_LINEAR;
+  }
   L.Cin = cin; L.Cout = cout; L.ksize = k;
   L.CC = conv_variant_cc(L.variant);
   L.CinPad = round_up(cin, L.CC);
