@@ -38,7 +38,7 @@ struct ConvArgs {
   int iHp, iWp, ipady, oHp, oWp, opady;
   size_t in_fs, out_fs, res_fs;   // per-frame strides in floats (tensors may be channel slices of concat buffers)
   int tiles_x, tiles_y, cout_tiles, nchunks;
-  int ntiles, tiles_per_xcd;   // pixel tiles of the launch (B * tiles_y * tiles_x) and ceil(ntiles / 8)
+  int ntiles, tiles_base, tiles_rem;   // pixel tiles of the launch (B * tiles_y * tiles_x) = 8 * tiles_base + tiles_rem
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int ct = slot % a.cout_tiles;
   const int tl = slot / a.cout_tiles;
-  int tile = xcd * a.tiles_per_xcd + tl;
-  if (tl >= a.tiles_per_xcd || tile >= a.ntiles) return;      // padding of the grid (whole workgroup, before any barrier)
+  // balanced contiguous ranges: XCD x owns tiles_base (+1 for x < tiles_rem) tiles starting at x * tiles_base + min(x, tiles_rem)
+  if (tl >= a.tiles_base + (xcd < a.tiles_rem ? 1 : 0)) return;   // padding of the grid (whole workgroup, before any barrier)
+  int tile = xcd * a.tiles_base + min(xcd, a.tiles_rem) + tl;     // < ntiles by construction
   const int tx = tile % a.tiles_x; tile /= a.tiles_x;
   const int ty = tile % a.tiles_y;
   const int b = tile / a.tiles_y;
@@ -263,9 +264,9 @@ static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   // 32-bit byte offsets inside a frame (epilogue): refused, not launched; the engine reports DANI_ERR_UNSUPPORTED
   if ((size_t)(L.cout_tiles * C::NCO + 8) * io.oHp * io.oWp >= ((size_t)1 << 30)) return false;
   a.ntiles = B * a.tiles_x * a.tiles_y;
-  a.tiles_per_xcd = (a.ntiles + 7) / 8;
+  a.tiles_base = a.ntiles / 8; a.tiles_rem = a.ntiles % 8;
   if (a.ntiles <= 0 || a.cout_tiles <= 0) return false;
-  const int grid = 8 * a.tiles_per_xcd * a.cout_tiles;      // 8 XCDs x (pixel tiles of one XCD) x cout tiles, see the kernel
+  const int grid = 8 * (a.tiles_base + (a.tiles_rem ? 1 : 0)) * a.cout_tiles;   // 8 XCDs x (largest share of pixel tiles) x cout tiles
   // reserve_lds: dynamic LDS the kernel never touches.  It only lowers how many of THESE workgroups fit on a CU, so that
   // a slot (registers, waves and the rest of the LDS) stays free for the workgroups of a concurrent stream (the fused
   // front-end: YOLO's chain of small dependent kernels next to SuperPoint's huge ones, sp_engine.cpp).
