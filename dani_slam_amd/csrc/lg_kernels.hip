@@ -746,6 +746,137 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
 }
 
 // ---------------------------------------------------------------------------------------------
+// Four-way key split for small problems (one or two pairs: fewer key-split workgroups than CUs): workgroup = ONE block of
+// 32 queries x 4 key quarters, wave w runs the online softmax over quarter w.  Half the serial length of attn_ks_kernel's
+// waves, twice the workgroups (264 at 2 x 1025 keypoints instead of 136 on 256 CUs).  No tile is shared between waves, so
+// each wave stages its own K / V tiles in its own LDS region and the tile loop has NO workgroup barrier; the four partial
+// (m, l, O) states meet once, at the end.  Dynamic LDS (4 x 2 tiles x 8448 B = 66 KiB, over the static limit).
+// ---------------------------------------------------------------------------------------------
+constexpr int ATK4_LDS_FLOATS = 4 * 2 * 64 * AT_STRIDE + LG_TAIL_MAX * 128;
+__global__ __launch_bounds__(256, 2) void attn_k4_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
+                                                         const LgSet* sets, int tail_slots, int cross, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float k4_lds[];
+  float* sKV = k4_lds;                                      // [key quarter][K | V][64 d][33]
+  float* sTK = k4_lds + 4 * 2 * 64 * AT_STRIDE;
+  int bx, head, bz;
+  const int tail_q = attn_role(tail_slots, bx, head, bz);
+  const LgSet st = sets[bz];
+  if (tail_q >= 0) { attn_tail_query(Q, K, V, O, ld, st, tail_q, head, cross, scale, sKV); return; }
+  const int np = (st.nmain + 31) & ~31;
+  const int q0 = bx * 32;
+  if (q0 >= np) return;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int kq = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const AttnKeys ks = attn_keys(st, cross);
+  const int k_off = ks.off, k_n = ks.nmain;
+  const int qi = q0 + j;
+  const int qtok = st.tok_off + qi;                          // q0 + 31 < np: every query of the block lies in the padded main region
+  const float* Qh = Q + (size_t)head * 64 * ld;
+  const float* Kh = K + (size_t)head * 64 * ld + k_off;
+  const float* Vh = V + (size_t)head * 64 * ld + k_off;
+  float* sK = sKV + (size_t)kq * 2 * 64 * AT_STRIDE;
+  float* sV = sK + 64 * AT_STRIDE;
+  const int ntail = ks.n - ks.nmain;
+  if (ntail > 0) {
+    attn_stage_tail_keys(K + (size_t)head * 64 * ld, V + (size_t)head * 64 * ld, ld, ks.tail_off, ntail, sTK);
+    __syncthreads();
+  }
+  float qreg[32];
+#pragma unroll
+  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * (scale * 1.44269504088896341f);
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; r++) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
+  float m = -1e30f, l = 0.0f;
+
+  const int ntiles = (k_n + 31) / 32, quarter = (ntiles + 3) / 4;
+  const int kt0 = kq * quarter, kt1 = min(kt0 + quarter, ntiles);
+  // this wave's staging of one key tile: K and V, 64 d x 32 keys each = 512 float4 per matrix, 8 + 8 per lane
+  f32x4 pk[8], pv[8];
+  int soff[8], loff[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int e = lane + 64 * u, d = e >> 3, q4 = e & 7;
+    soff[u] = d * ld + 4 * q4;
+    loff[u] = d * AT_STRIDE + 4 * q4;
+  }
+#define ATK4_PREFETCH(kt_)                                                             \
+  {                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) {                                    \
+      pk[u] = *reinterpret_cast<const f32x4*>(Kh + (size_t)soff[u] + (kt_) * 32);      \
+      pv[u] = *reinterpret_cast<const f32x4*>(Vh + (size_t)soff[u] + (kt_) * 32);      \
+    }                                                                                  \
+  }
+  if (kt0 < kt1) ATK4_PREFETCH(kt0);
+  for (int kt = kt0; kt < kt1; kt++) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) { sK[loff[u] + c] = pk[u][c]; sV[loff[u] + c] = pv[u][c]; }
+    }
+    if (kt + 1 < kt1) ATK4_PREFETCH(kt + 1);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = 0.0f;
+    attn_qk_tile(sK, qreg, s, j, h);
+    const int kbase = kt * 32;
+    if (kbase + 32 > k_n) {
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (kbase + acc_row(r, h) >= k_n) s[r] = -1e30f;
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    float ls = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); ls += s[r]; }
+    if (__ballot(m_new > m)) {
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    }
+    l += ls;
+    m = m_new;
+    attn_pv_tile(sV, s, o, j, h);
+  }
+#undef ATK4_PREFETCH
+  if (ntail > 0 && kq == 3) attn_tail_keys(sTK, ntail, qreg, o, m, l, h);   // the last quarter is the shortest
+  // ---- merge: quarters 1..3 leave their state in their OWN tile region (64 lanes x 34 floats), quarter 0 folds them in
+  if (kq != 0) {
+    float* p = sK + lane * 34;
+    p[0] = m; p[1] = l;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { p[2 + r] = o[0][r]; p[18 + r] = o[1][r]; }
+  }
+  __syncthreads();
+  if (kq == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      const float* p = sKV + (size_t)w * 2 * 64 * AT_STRIDE + lane * 34;
+      const float m1 = p[0], l1 = p[1];
+      const float mm = fmaxf(m, m1);
+      const float a0 = __builtin_amdgcn_exp2f(m - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+      l = l * a0 + l1 * a1;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { o[0][r] = o[0][r] * a0 + p[2 + r] * a1; o[1][r] = o[1][r] * a0 + p[18 + r] * a1; }
+      m = mm;
+    }
+    const float lt = l + __shfl_xor(l, 32);
+    const float inv = (lt > 0.0f && qi < st.nmain) ? 1.0f / lt : 0.0f;   // padding queries and empty key sets -> 0
+    float* Oh = O + (size_t)head * 64 * ld + st.tok_off + qi;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      Oh[(size_t)acc_row(r, h) * ld] = o[0][r] * inv;
+      Oh[(size_t)(32 + acc_row(r, h)) * ld] = o[1][r] * inv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // attn_x3_kernel: attn_ks_kernel with both contractions on the bf16 matrix cores at f32 accuracy (x3_common.h; the
 // DANI_LG_GEMM_BF16X3_ALL option).  Same workgroup shape (64 queries = 2 query blocks x 2 key halves), same online
 // softmax in f32, same tail-key / tail-query / merge code.  What changes:
@@ -1135,7 +1266,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3w_kernel(const float* Q, const 
   }
 }
 
-int g_attn_force = 0;   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel, 4 = attn_x3w_kernel
+int g_attn_force = 0;   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel, 4 = attn_x3w_kernel, 5 = attn_k4_kernel
 
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_mp, int max_tail, int cross, float scale, hipStream_t s, int x3) {
@@ -1149,7 +1280,12 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
   // At 16 x 1025 keypoints (512 workgroups = one round): 150.1 vs 156.0 us (tools/probes/attn_bench.hip).
   else if (g_attn_force != 1 && (g_attn_force == 2 || ((max_mp + 127) / 128) * 4 * nsets >= 512))
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
-  else
+  // fewer key-split workgroups than CUs (one pair of 1024 keypoints: 136): four key quarters per 32-query block instead
+  else if (g_attn_force == 5 || (g_attn_force == 0 && ((max_mp + 63) / 64) * 4 * nsets <= 256)) {
+    static bool attr_set = false;   // idempotent; a race between two first callers sets the same value twice
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_k4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATK4_LDS_FLOATS * 4); attr_set = true; }
+    hipLaunchKernelGGL(attn_k4_kernel, dim3((max_mp + 31) / 32 + max_tail, 4, nsets), dim3(256), (size_t)ATK4_LDS_FLOATS * 4, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+  } else
     hipLaunchKernelGGL(attn_ks_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
 }
 

@@ -34,6 +34,26 @@ __device__ __forceinline__ void lin_epilogue(const Acc& acc, int row0, int h, in
   auto at = [](const float* base, unsigned off) -> const float& { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); };
   auto at_w = [](float* base, unsigned off) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off); };
   const bool rot = row0 < e.rot_rows;
+  // Loads first, all of them, each kind behind ONE wave-uniform branch: written as "if (rot) load; ... if (res) load" inside
+  // the row loop, hipcc branches around every pair of loads and waits vmcnt(0) after it -- 16 dependent L2 round trips per
+  // wave at the very end of a workgroup, where nothing else on the CU can cover them.
+  float cs[8], sn[8], rv[16];
+  if (rot) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int rr = row0 + ((2 * i) & 3) + 8 * ((2 * i) >> 2);
+      const size_t ip = (size_t)((rr & 63) >> 1) * e.ld;                 // uniform
+      cs[i] = at(e.cosb + ip, rot_off); sn[i] = at(e.sinb + ip, rot_off);
+    }
+  }
+  if (e.res) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int rr = row0 + (r & 3) + 8 * (r >> 2);
+      const float* rp = e.res + (size_t)rr * e.ld;
+      rv[r] = at(rp, lane_off); rv[r + 1] = at(rp, lane_off + ldb);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
     const int rr = row0 + (r & 3) + 8 * (r >> 2);                        // uniform; this lane's rows are rr + 4h, +1
@@ -43,18 +63,13 @@ __device__ __forceinline__ void lin_epilogue(const Acc& acc, int row0, int h, in
       v0 += b[4 * h]; v1 += b[4 * h + 1];
     }
     if (rot) {
-      const size_t ip = (size_t)((rr & 63) >> 1) * e.ld;                 // uniform
-      const float c = at(e.cosb + ip, rot_off), s = at(e.sinb + ip, rot_off);
+      const float c = cs[r >> 1], s = sn[r >> 1];
       const float r0 = v0 * c - v1 * s, r1 = v1 * c + v0 * s;            // t*cos + rotate_half(t)*sin
       v0 = r0; v1 = r1;
     }
     v0 *= e.alpha; v1 *= e.alpha;
-    const size_t rb = (size_t)rr * e.ld;                                 // uniform
-    if (e.res) {
-      const float* rp = e.res + rb;
-      v0 += at(rp, lane_off); v1 += at(rp, lane_off + ldb);
-    }
-    float* yp = e.y + rb;
+    if (e.res) { v0 += rv[r]; v1 += rv[r + 1]; }
+    float* yp = e.y + (size_t)rr * e.ld;                                 // uniform
     at_w(yp, lane_off) = v0; at_w(yp, lane_off + ldb) = v1;
   }
 }

@@ -124,7 +124,8 @@ def test_batch_equals_single(engine, lg_weights):
     for p, (k0, d0, k1, d1, _) in enumerate(pairs):
         m, s = engine.lg_match(k0, d0, k1, d1, SIZE, SIZE, 0.05)
         assert np.array_equal(res[p][0], m)
-        np.testing.assert_allclose(res[p][1], s, rtol=0, atol=1e-6)
+        # the batch of three takes attn_ks_kernel, a single pair attn_k4_kernel: two key splits, two summation orders
+        np.testing.assert_allclose(res[p][1], s, rtol=0, atol=1e-4)
 
 
 def test_large_batch_kernel_with_ragged_sets(lg_weights, sp_weights):

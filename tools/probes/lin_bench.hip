@@ -2,11 +2,27 @@
 // LightGlue layer shapes for several token counts.  Usage: lin_bench [T ...]
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I ../../dani_slam_amd/csrc -o lin_bench lin_bench.hip
 #include "../../dani_slam_amd/csrc/lg_kernels.hip"
+#include "lin_ring_kernels.inc"
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace dani;
+// tt: 0 / 64 / 128 / 256 = the product launcher (with its tuning hook), >= 10000 = a ring variant (lin_ring_kernels.inc)
+static bool launch_any(int tt, const float* x0, int K0, const float* x1, int K1, const float* w, const float* b, float* y, int OUT, int T,
+                       int ld, const float* res, const float* cosb, const float* sinb, int rot, float alpha) {
+  if (tt >= 10000) return launch_linear_variant(tt, x0, K0, x1, K1, w, b, y, OUT, T, ld, res, cosb, sinb, rot, alpha, 0);
+  g_lin_force_tt = tt;
+  return launch_linear_fm(x0, K0, x1, K1, w, b, y, OUT, T, ld, res, cosb, sinb, rot, alpha, 0);
+}
+__global__ void fill_rand(float* p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u ^ (seed * 0x9E3779B9u); x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    p[i] = ((int)(x & 0xFFFF) - 32768) * (1.0f / 65536.0f);
+  }
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
@@ -18,6 +34,30 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&X, (size_t)1024 * ld * 4)); CK(hipMalloc(&Y, (size_t)768 * ld * 4)); CK(hipMalloc(&Wt, (size_t)768 * 512 * 4));
   CK(hipMalloc(&Bs, 768 * 4)); CK(hipMalloc(&C, (size_t)64 * ld * 4));
   CK(hipMemset(X, 0, (size_t)1024 * ld * 4)); CK(hipMemset(Wt, 0, (size_t)768 * 512 * 4)); CK(hipMemset(Bs, 0, 768 * 4)); CK(hipMemset(C, 0, (size_t)64 * ld * 4));
+  // random operands (zero-filled ones read high: the MFMA units draw less power on zeros)
+  hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, 0, X, (size_t)1024 * ld, 1u);
+  hipLaunchKernelGGL(fill_rand, dim3(1024), dim3(256), 0, 0, Wt, (size_t)768 * 512, 2u);
+  hipLaunchKernelGGL(fill_rand, dim3(1), dim3(256), 0, 0, Bs, (size_t)768, 3u);
+  hipLaunchKernelGGL(fill_rand, dim3(1024), dim3(256), 0, 0, C, (size_t)64 * ld, 4u);
+  CK(hipDeviceSynchronize());
+  if (getenv("LIN_CHECK")) {   // ring variants against the shipped kernel, bit for bit, on every shape
+    const int T = 16416;
+    float* Y2; CK(hipMalloc(&Y2, (size_t)768 * ld * 4));
+    std::vector<float> r0((size_t)768 * T), r1((size_t)768 * T);
+    struct S2 { int out, k0, k1, rot; bool res; } sh2[] = {{768, 256, 0, 512, false}, {512, 256, 256, 0, false}, {256, 512, 0, 0, true}};
+    for (const S2& sh : sh2)
+      for (int tt : {10323, 20164, 20163, 20322}) {
+        launch_any(0, X, sh.k0, sh.k1 ? X + (size_t)512 * ld : nullptr, sh.k1, Wt, Bs, Y, sh.out, T, ld, sh.res ? X + (size_t)600 * ld : nullptr, C, C + (size_t)32 * ld, sh.rot, 0.7f);
+        launch_any(tt, X, sh.k0, sh.k1 ? X + (size_t)512 * ld : nullptr, sh.k1, Wt, Bs, Y2, sh.out, T, ld, sh.res ? X + (size_t)600 * ld : nullptr, C, C + (size_t)32 * ld, sh.rot, 0.7f);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy2D(r0.data(), (size_t)T * 4, Y, (size_t)ld * 4, (size_t)T * 4, sh.out, hipMemcpyDeviceToHost));
+        CK(hipMemcpy2D(r1.data(), (size_t)T * 4, Y2, (size_t)ld * 4, (size_t)T * 4, sh.out, hipMemcpyDeviceToHost));
+        size_t bad = 0; double sum = 0, maxd = 0;
+        for (size_t i = 0; i < (size_t)sh.out * T; i++) { bad += memcmp(&r0[i], &r1[i], 4) != 0; sum += fabs(r0[i]); maxd = std::max(maxd, (double)fabs(r0[i] - r1[i])); }
+        printf("check out=%d K=%d variant %d: %zu of %zu differ (mean |y| %.3f, max |diff| %.3g)\n", sh.out, sh.k0 + sh.k1, tt, bad, (size_t)sh.out * T, sum / ((double)sh.out * T), maxd);
+      }
+    g_lin_force_tt = 0;
+  }
   struct Shape { const char* name; int out, k0, k1, rot; bool res; } shapes[] = {
       {"Wqkv   768 <- 256 (+rotary)", 768, 256, 0, 512, false}, {"qk|v   512 <- 256", 512, 256, 0, 0, false},
       {"ffn.0  512 <- 256+256", 512, 256, 256, 0, false},        {"ffn.3  256 <- 512 (+res)", 256, 512, 0, 0, true}};
@@ -27,13 +67,12 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   for (const Shape& sh : shapes)
     for (int T : Ts)
-    for (int tt : {0, 64, 128, 256}) {
-      g_lin_force_tt = tt;
+    for (int tt : {0, 10322, 10323, 10163, 10164, 10642, 20164, 20163, 20322}) {
       std::vector<double> us;
       for (int rd = 0; rd < 7; rd++) {
         CK(hipEventRecord(a, 0));
         for (int i = 0; i < 10; i++)
-          launch_linear_fm(X, sh.k0, sh.k1 ? X + (size_t)512 * ld : nullptr, sh.k1, Wt, Bs, Y, sh.out, T, ld, sh.res ? Y : nullptr, C, C + (size_t)32 * ld, sh.rot, 1.0f, 0);
+          launch_any(tt, X, sh.k0, sh.k1 ? X + (size_t)512 * ld : nullptr, sh.k1, Wt, Bs, Y, sh.out, T, ld, sh.res ? Y : nullptr, C, C + (size_t)32 * ld, sh.rot, 1.0f);
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms = 0;
@@ -42,7 +81,7 @@ int main(int argc, char** argv) {
       }
       std::sort(us.begin(), us.end());
       const double fl = 2.0 * sh.out * (sh.k0 + sh.k1) * (double)T;
-      printf("%-30s T=%6d TT=%3d  median %7.1f us  min %7.1f   %6.1f TFLOP/s\n", sh.name, T, tt, us[3], us[0], fl / (us[3] * 1e-6) / 1e12);
+      printf("%-30s T=%6d TT=%5d  median %7.1f us  min %7.1f   %6.1f TFLOP/s\n", sh.name, T, tt, us[3], us[0], fl / (us[3] * 1e-6) / 1e12);
     }
   return 0;
 }
