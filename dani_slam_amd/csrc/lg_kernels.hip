@@ -21,6 +21,7 @@
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include "lin_epilogue.h"
 #include "x3_common.h"
 
@@ -55,6 +56,7 @@ struct LinArgs {
   float* y; const float* res; const float* cosb; const float* sinb;
   int OUT, T, ld, rot_rows;
   float alpha;
+  int ksplit;   // 64-token kernel: split K between the wave pairs of a tail tile of <= 32 tokens (DANI_LIN_NO_KSPLIT=1 turns it off)
 };
 
 constexpr int LIN_KC = 32, LIN_NCO = 64;
@@ -84,7 +86,13 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   const int tok0 = tile * TT;
   const int K = a.K0 + a.K1, nchunks = K / KC;
   const float* wt = a.w + (size_t)ot * K * LIN_NCO;
-  const int wtok = (TT >= 128) ? wave * (TT / 4) : (wave & 1) * 32;   // wave's first token inside the tile
+  // Tail tile of the 64-token kernel (at most 32 tokens left: the shared tail region of a batch of ~1025-keypoint sets):
+  // its two token-half waves would idle while the other two run the whole K loop, and the workgroup, which lands as a
+  // FIFTH one on a CU that already holds four, stretches that CU's launch by 25 %.  Instead both wave pairs take the first
+  // 32 tokens and split every K chunk between them (k-pair groups alternate); the halves meet in LDS at the end.
+  const bool ksplit = (TT == 64) && a.ksplit && (a.T - tok0 <= 32);    // uniform per workgroup
+  const int kh = ksplit ? (wave & 1) : 0;
+  const int wtok = (TT >= 128) ? wave * (TT / 4) : (ksplit ? 0 : (wave & 1) * 32);   // wave's first token inside the tile
   const int wout = (TT >= 128) ? 0 : (wave >> 1) * 32;                 // wave's first output row inside the 64
 
   f32x16 acc[NCB][NTB];
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float bv = a.bias[ot * LIN_NCO + wout + cb * 32 + acc_row(r, h)];
+      const float bv = kh ? 0.0f : a.bias[ot * LIN_NCO + wout + cb * 32 + acc_row(r, h)];
 #pragma unroll
       for (int tb = 0; tb < NTB; tb++) acc[cb][tb][r] = bv;
       acc2[r] = 0.0f;
@@ -128,45 +136,67 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
     if (ch + 1 < nchunks) LIN_PREFETCH(ch + 1);
     // Operand reads run PD k-pair groups ahead of the MFMAs that use them (groups of 2 k-pairs: the compiler merges
     // their reads into ds_read2st64): left alone, hipcc sinks every read next to its MFMA and waits on it.
-    constexpr int G = 2, NG = KC / 2 / G, PD = 1;   // measured best of G in {1, 2, 4, 8} x PD in {1, 2} (lin_bench)
-    float av[NG][G][NCB], bv[NG][G][NTB];
-    auto rd = [&](int g) {
+    // STEP = 2: the k-split tail tile, this wave takes every second group starting at its own (pointers pre-offset).
+    auto chunk = [&](auto step_tag, const float* bA_, const float* bB_) {
+      constexpr int STEP = decltype(step_tag)::value;
+      constexpr int G = 2, NG = KC / 2 / G / STEP, PD = 1;   // measured best of G in {1, 2, 4, 8} x PD in {1, 2} (lin_bench)
+      float av[NG][G][NCB], bv[NG][G][NTB];
+      auto rd = [&](int g) {
 #pragma unroll
-      for (int q = 0; q < G; q++) {
-        const int kp = g * G + q;
+        for (int q = 0; q < G; q++) {
+          const int kp = g * STEP * G + q;
 #pragma unroll
-        for (int cb = 0; cb < NCB; cb++) av[g][q][cb] = bA[(kp * 2) * LIN_NCO + cb * 32];
+          for (int cb = 0; cb < NCB; cb++) av[g][q][cb] = bA_[(kp * 2) * LIN_NCO + cb * 32];
 #pragma unroll
-        for (int tb = 0; tb < NTB; tb++) bv[g][q][tb] = bB[(kp * 2) * TT + tb * 32];
+          for (int tb = 0; tb < NTB; tb++) bv[g][q][tb] = bB_[(kp * 2) * TT + tb * 32];
+        }
+      };
+#pragma unroll
+      for (int g = 0; g < PD; g++) rd(g);
+#pragma unroll
+      for (int g = 0; g < NG; g++) {
+        if (g + PD < NG) rd(g + PD);
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+          if constexpr (NCB * NTB == 1) {
+            if (q & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][0], bv[g][q][0], acc2, 0, 0, 0);
+            else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][0], bv[g][q][0], acc[0][0], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+              for (int tb = 0; tb < NTB; tb++)
+                acc[cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][cb], bv[g][q][tb], acc[cb][tb], 0, 0, 0);
+          }
+        }
+        // one group of LDS reads (next group's operands), then this group's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, G * (NCB + NTB), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, G * NCB * NTB, 0);
       }
     };
-#pragma unroll
-    for (int g = 0; g < PD; g++) rd(g);
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      if (g + PD < NG) rd(g + PD);
-#pragma unroll
-      for (int q = 0; q < G; q++) {
-        if constexpr (NCB * NTB == 1) {
-          if (q & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][0], bv[g][q][0], acc2, 0, 0, 0);
-          else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][0], bv[g][q][0], acc[0][0], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-            for (int tb = 0; tb < NTB; tb++)
-              acc[cb][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][q][cb], bv[g][q][tb], acc[cb][tb], 0, 0, 0);
-        }
-      }
-      // one group of LDS reads (next group's operands), then this group's MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, G * (NCB + NTB), 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, G * NCB * NTB, 0);
+    if constexpr (TT == 64) {
+      if (ksplit) chunk(std::integral_constant<int, 2>(), bA + kh * 4 * LIN_NCO, bB + kh * 4 * TT);
+      else chunk(std::integral_constant<int, 1>(), bA, bB);
+    } else {
+      chunk(std::integral_constant<int, 1>(), bA, bB);
     }
   }
 #undef LIN_PREFETCH
   if constexpr (NCB * NTB == 1) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[0][0][r] += acc2[r];
+    if (ksplit) {   // fold the second K half into the first through LDS (the chunk buffers are free after the barrier)
+      __syncthreads();
+      float* xch = lds + ((wave >> 1) * 64 + lane) * 17;
+      if (kh) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) xch[r] = acc[0][0][r];
+      }
+      __syncthreads();
+      if (kh) return;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[0][0][r] += xch[r];
+    }
   }
 
   LinEpi ep;
@@ -188,6 +218,8 @@ bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   LinArgs a;
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w_packed; a.bias = bias_packed; a.y = y; a.res = res;
   a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;
+  static const int ksplit_on = getenv("DANI_LIN_NO_KSPLIT") ? 0 : 1;
+  a.ksplit = ksplit_on;
   const int otiles = (OUT + LIN_NCO - 1) / LIN_NCO;
   // The 64-token tile (90 VGPRs, 32 KB LDS, 5 workgroups per CU) beats the 128- and 256-token ones (128 / 148 VGPRs,
   // 48 KB, 3 per CU) on every LightGlue shape from 16 k to 66 k tokens by 7-17 % (tools/probes/lin_bench.hip), so it is
