@@ -43,11 +43,24 @@ struct ConvArgs {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
 
+#ifdef DANI_CONV_STAMPS
+// Debug build only (make STAMPS=1, tools/debug/conv_stamps.py): workgroup 0 of every conv launch records core-clock and
+// 100 MHz wall-clock stamps of its chunk loop into g_conv_stamps[launch][..]: [0] = chunks, [1] wall at entry, [2] clock at
+// entry, then per chunk (clock when the chunk is ready in LDS, clock when its MFMAs are issued), [92] = grid, [93] = 1000 ACT + 100 KS +
+// 10 S + accumulators per wave, last two = clock, wall at exit.
+__device__ unsigned long long g_conv_stamps[256 * 96];
+__device__ int g_conv_launches;
+#define STAMP(i_, v_) do { if (stamp_row >= 0 && (i_) < 96) g_conv_stamps[stamp_row * 96 + (i_)] = (v_); } while (0)
+#else
+#define STAMP(i_, v_) do { } while (0)
+#endif
+
 template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2>
 struct Cfg {
   static constexpr int KS = KS_, S = S_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_, ACT = ACT_;
   static constexpr bool POOL = POOL_;
   static constexpr int T = KS * KS;
+  static constexpr bool HAS_RES = (KS == 3 && S == 1 && ACT == ACT_SILU);   // only YOLOv5's bottleneck cv2 takes a shortcut operand
   static constexpr int PAD = (KS == 1) ? 0 : (KS == 3) ? 1 : 2;   // 1x1 p0, 3x3 p1, 6x6 p2 (YOLOv5 stem)
   static constexpr int NCB = NCB_, NCO = 32 * NCB_;   // cout blocks per wave / couts per workgroup
   static constexpr int TH = 4 * NPB * PBH, TW = PBW;   // 4 waves stacked vertically (output pixels)
@@ -94,6 +107,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   const int b = tile / a.tiles_y;
   const int y0 = ty * C::TH, x0 = tx * C::TW;
 
+#ifdef DANI_CONV_STAMPS
+  int stamp_row = -1;
+  if (blockIdx.x == 0 && tid == 0) { stamp_row = atomicAdd(&g_conv_launches, 1); if (stamp_row >= 256) stamp_row = -1; }
+  STAMP(0, (unsigned long long)a.nchunks); STAMP(1, __builtin_amdgcn_s_memrealtime()); STAMP(2, __builtin_readcyclecounter());
+  STAMP(92, (unsigned long long)gridDim.x); STAMP(93, (unsigned long long)(C::ACT * 1000 + C::KS * 100 + C::S * 10 + C::NCB * C::NPB));
+#endif
   const size_t iplane = (size_t)a.iHp * a.iWp;
   const float* inb = a.in + (size_t)b * a.in_fs;
   // first staged element (padded coordinates): row S*y0 + ipady - PAD, column S*x0 + GX0
@@ -150,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     for (int t = 0; t < C::NW; t++)
       if (tid + 256 * t < C::W_F4) reinterpret_cast<f32x4*>(sW)[tid + 256 * t] = pw[t];
     __syncthreads();
+    STAMP(3 + 2 * ch, __builtin_readcyclecounter());
     if (ch + 1 < a.nchunks) DANI_PREFETCH(ch + 1);
 
 #pragma unroll
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
             for (int pb = 0; pb < C::NPB; pb++)
               acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[pb], acc[cb][pb], 0, 0, 0);
         }
+    STAMP(4 + 2 * ch, __builtin_readcyclecounter());
   }
 
 #undef DANI_PREFETCH
@@ -197,6 +218,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
       }
   } else {
     const float* resb = a.res ? a.res + (size_t)b * a.res_fs : nullptr;
+    // Residual operands first, all of them behind ONE uniform branch: loaded next to their use inside the loop below, each
+    // load sits in its own branch with a vmcnt(0) behind it -- 16 dependent round trips per accumulator at the very end of
+    // the workgroup (tools/debug/conv_stamps.py: 11-16 k cycles of epilogue in the shortcut layers against 5 k in the others).
+    float rv[C::HAS_RES ? C::NPB : 1][C::HAS_RES ? C::NCB : 1][16];
+    if (C::HAS_RES && resb) {
+#pragma unroll
+      for (int pb = 0; pb < C::NPB; pb++) {
+        const int y = y0 + wave * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
+        const bool ok = y < a.H && x < a.W;
+        const unsigned lane_off = 4u * ((unsigned)(y + a.opady) * (unsigned)a.oWp + (unsigned)(x + PADX) + 4u * (unsigned)h * oplane);
+#pragma unroll
+        for (int cb = 0; cb < C::NCB; cb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int cu = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2);
+            rv[pb][cb][r] = (ok && cu + 4 * h < a.Cout) ? at_r(resb + (size_t)cu * oplane, lane_off) : 0.0f;
+          }
+      }
+    }
 #pragma unroll
     for (int pb = 0; pb < C::NPB; pb++) {
       const int y = y0 + wave * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
@@ -210,14 +250,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
           if (C::ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
           if (C::ACT == ACT_SILU) v = v / (1.0f + dani_expf(-v));
           const int cu = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2);   // uniform; this lane's channel is cu + 4h
-          if (ok && cu + 4 * h < a.Cout) {
-            const size_t cbase = (size_t)cu * oplane;
-            if (resb) v = at_r(resb + cbase, lane_off) + v;
-            at_w(outb + cbase, lane_off) = v;
-          }
+          if constexpr (C::HAS_RES) { if (resb) v = rv[pb][cb][r] + v; }
+          if (ok && cu + 4 * h < a.Cout) at_w(outb + (size_t)cu * oplane, lane_off) = v;
         }
     }
   }
+  STAMP(94, __builtin_readcyclecounter()); STAMP(95, __builtin_amdgcn_s_memrealtime());
 }
 
 //                         KS S PBH PBW NPB CC  ACT       POOL
@@ -266,6 +304,7 @@ static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   a.ntiles = B * a.tiles_x * a.tiles_y;
   a.tiles_base = a.ntiles / 8; a.tiles_rem = a.ntiles % 8;
   if (a.ntiles <= 0 || a.cout_tiles <= 0) return false;
+  if (io.res && !C::HAS_RES) return false;   // this instantiation has no residual path
   const int grid = 8 * (a.tiles_base + (a.tiles_rem ? 1 : 0)) * a.cout_tiles;   // 8 XCDs x (largest share of pixel tiles) x cout tiles
   // reserve_lds: dynamic LDS the kernel never touches.  It only lowers how many of THESE workgroups fit on a CU, so that
   // a slot (registers, waves and the rest of the LDS) stays free for the workgroups of a concurrent stream (the fused
@@ -312,6 +351,18 @@ bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& 
   io.in_fs = in.frame_stride(); io.out_fs = out.frame_stride(); io.res_fs = 0;
   return launch_conv_io(L, io, B, s, reserve_lds);
 }
+
+#ifdef DANI_CONV_STAMPS
+}  // namespace dani
+extern "C" __attribute__((visibility("default"))) int dani_debug_conv_stamps(unsigned long long* out, int reset) {
+  if (reset) { int z = 0; return (int)hipMemcpyToSymbol(HIP_SYMBOL(dani::g_conv_launches), &z, 4); }
+  int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(dani::g_conv_launches), 4) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dani::g_conv_stamps), sizeof(unsigned long long) * 256 * 96) != hipSuccess) return -1;
+  return n;
+}
+namespace dani {
+#endif
 
 const char* conv_kernel_name(ConvVariant v) {
   switch (v) {
