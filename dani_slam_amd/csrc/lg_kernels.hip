@@ -61,6 +61,16 @@ struct LinArgs {
 
 constexpr int LIN_KC = 32, LIN_NCO = 64;
 
+#ifdef DANI_CONV_STAMPS
+// Debug build only (tools/probes/lin_bench.hip with -DDANI_CONV_STAMPS): wall clock (100 MHz) and core clock of workgroup 0,
+// and per workgroup the wall-clock ticks (10 ns) at entry, first chunk staged, K loop done, exit.
+__device__ unsigned long long g_lin_stamps[4];
+__device__ unsigned int g_lin_trace[8192 * 4];
+#define LIN_TRACE(k_) do { if (tid == 0 && blockIdx.x < 8192) g_lin_trace[blockIdx.x * 4 + (k_)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LIN_TRACE(k_) do { } while (0)
+#endif
+
 // TT = tokens per workgroup.  256: wave = 64 out x 64 tok (2x2 accumulators); 128: wave = 64 out x 32 tok (2x1);
 // 64: waves arranged 2x2, wave = 32 out x 32 tok (1x1).  Smaller tiles trade operand reuse for more workgroups:
 // with ~17k tokens and 256 outputs a 256-token tile gives only 264 workgroups for 256 CUs (two rounds, 50 % idle).
@@ -84,6 +94,10 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   const int tile = (slot / otiles) * 8 + xcd, ot = slot % otiles;
   if (tile >= ntiles) return;
   const int tok0 = tile * TT;
+#ifdef DANI_CONV_STAMPS
+  if (blockIdx.x == 0 && tid == 0) { g_lin_stamps[0] = __builtin_amdgcn_s_memrealtime(); g_lin_stamps[1] = __builtin_readcyclecounter(); }
+#endif
+  LIN_TRACE(0);
   const int K = a.K0 + a.K1, nchunks = K / KC;
   const float* wt = a.w + (size_t)ot * K * LIN_NCO;
   // Tail tile of the 64-token kernel (at most 32 tokens left: the shared tail region of a batch of ~1025-keypoint sets):
@@ -133,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
 #pragma unroll
     for (int u = 0; u < NWF; u++) reinterpret_cast<f32x4*>(sW)[tid + 256 * u] = pw[u];
     __syncthreads();
+    if (ch == 0) LIN_TRACE(1);
     if (ch + 1 < nchunks) LIN_PREFETCH(ch + 1);
     // Operand reads run PD k-pair groups ahead of the MFMAs that use them (groups of 2 k-pairs: the compiler merges
     // their reads into ds_read2st64): left alone, hipcc sinks every read next to its MFMA and waits on it.
@@ -199,6 +214,10 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
     }
   }
 
+#ifdef DANI_CONV_STAMPS
+  if (blockIdx.x == 0 && tid == 0) { g_lin_stamps[2] = __builtin_readcyclecounter(); g_lin_stamps[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+  LIN_TRACE(2);
   LinEpi ep;
   ep.y = a.y; ep.res = a.res; ep.cosb = a.cosb; ep.sinb = a.sinb; ep.bias = nullptr; ep.ld = a.ld; ep.rot_rows = a.rot_rows; ep.alpha = a.alpha;
 #pragma unroll
@@ -207,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) lin_epilogue<false>(acc[cb][tb], ot * LIN_NCO + wout + cb * 32, h, tok, tok < a.T, ep);
   }
+  LIN_TRACE(3);
 }
 
 int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = the 64-token tile)

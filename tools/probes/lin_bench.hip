@@ -1,6 +1,7 @@
 // Times the PRODUCT feature-major linear launch (dani_slam_amd/csrc/lg_kernels.hip, included as source) on the
 // LightGlue layer shapes for several token counts.  Usage: lin_bench [T ...]
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I ../../dani_slam_amd/csrc -o lin_bench lin_bench.hip
+//        (add -DDANI_CONV_STAMPS for the core clock of workgroup 0 and the entry / first-chunk / loop-done / exit timeline of every workgroup)
 #include "../../dani_slam_amd/csrc/lg_kernels.hip"
 #include "lin_ring_kernels.inc"
 #include <algorithm>
@@ -67,7 +68,7 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
   for (const Shape& sh : shapes)
     for (int T : Ts)
-    for (int tt : {0, 10322, 10323, 10163, 10164, 10642, 20164, 20163, 20322}) {
+    for (int tt : {0}) {
       std::vector<double> us;
       for (int rd = 0; rd < 7; rd++) {
         CK(hipEventRecord(a, 0));
@@ -81,7 +82,33 @@ int main(int argc, char** argv) {
       }
       std::sort(us.begin(), us.end());
       const double fl = 2.0 * sh.out * (sh.k0 + sh.k1) * (double)T;
-      printf("%-30s T=%6d TT=%5d  median %7.1f us  min %7.1f   %6.1f TFLOP/s\n", sh.name, T, tt, us[3], us[0], fl / (us[3] * 1e-6) / 1e12);
+      printf("%-30s T=%6d TT=%5d  median %7.1f us  min %7.1f   %6.1f TFLOP/s", sh.name, T, tt, us[3], us[0], fl / (us[3] * 1e-6) / 1e12);
+#ifdef DANI_CONV_STAMPS
+      if (tt < 10000) {   // workgroup 0 of the last launch: its main loop in core clocks against the 100 MHz wall clock
+        unsigned long long st[4];
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(dani::g_lin_stamps), sizeof(st)));
+        const double wall_us = (double)(st[3] - st[0]) / 100.0;
+        printf("   wg0 main loop %.1f us at %.2f GHz", wall_us, (double)(st[2] - st[1]) / wall_us / 1e3);
+        // every workgroup of the last launch: when it entered, had its first chunk staged, left the K loop, exited (us after the first entry)
+        const int nwg = std::min(8192, (int)(((T + 63) / 64 + 7) / 8 * 8 * ((sh.out + 63) / 64)));
+        std::vector<unsigned> tr((size_t)8192 * 4);
+        CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(dani::g_lin_trace), tr.size() * 4));
+        std::vector<double> col[4];
+        unsigned t0 = 0xffffffffu;
+        const int ntl = (T + 63) / 64, otl = (sh.out + 63) / 64;
+        auto live = [&](int b) { const int slot = b >> 3, tile = (slot / otl) * 8 + (b & 7); return tile < ntl; };
+        for (int b = 0; b < nwg; b++) if (live(b)) t0 = std::min(t0, tr[(size_t)b * 4]);
+        for (int b = 0; b < nwg; b++) if (live(b)) for (int k = 0; k < 4; k++) col[k].push_back((double)(tr[(size_t)b * 4 + k] - t0) / 100.0);
+        printf("\n      %zu workgroups; us after the first entry, min / p10 / p50 / p90 / max:", col[0].size());
+        const char* nm[4] = {"entry", "first chunk staged", "K loop done", "exit"};
+        for (int k = 0; k < 4; k++) {
+          std::sort(col[k].begin(), col[k].end());
+          const size_t n = col[k].size();
+          printf("\n        %-20s %6.1f %6.1f %6.1f %6.1f %6.1f", nm[k], col[k][0], col[k][n / 10], col[k][n / 2], col[k][n * 9 / 10], col[k][n - 1]);
+        }
+      }
+#endif
+      printf("\n");
     }
   return 0;
 }
