@@ -402,19 +402,29 @@ constexpr int AT_STRIDE = 33;
 // ONE XCD, in consecutive dispatch slots (so they are resident together and share the tiles in that L2): with
 // L = 8 * slot + xcd, group = 8 * (slot / gx) + xcd and tile = slot % gx.  Groups beyond the last multiple of 8 keep the
 // plain order.  Speed only: any placement computes the same values.
-__device__ __forceinline__ int attn_role(int tail_slots, int& bx, int& by, int& bz) {
+__device__ __forceinline__ int attn_role(int tail_slots_signed, int& bx, int& by, int& bz) {
   bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+  // Sign of the argument: > 0 = the tail-query workgroups take the LAST ids of the launch (large batches: the main tiles
+  // fill every resident slot, and short workgroups dispatched first delay as many MFMA workgroups: 150 -> 156 us per launch
+  // at 16 x 1025 keypoints); < 0 = the FIRST ids (attn_k4_kernel: about one main workgroup per CU, so the tail queries'
+  // ~15 us of VALU work run beside the main tiles from the start instead of after them).
+  const bool tail_first = tail_slots_signed < 0;
+  const int tail_slots = tail_first ? -tail_slots_signed : tail_slots_signed;
   const int gx = gridDim.x - tail_slots, gy = gridDim.y;
-  const int L = blockIdx.x + gridDim.x * (blockIdx.y + gy * blockIdx.z), ngroups = gy * gridDim.z, nmain = gx * ngroups;
-  if (L < nmain) {
+  const int ngroups = gy * gridDim.z, nmain = gx * ngroups, ntail = tail_slots * ngroups;
+  int L = blockIdx.x + gridDim.x * (blockIdx.y + gy * blockIdx.z);
+  int t = -1;
+  if (tail_first) { if (L < ntail) t = L; else L -= ntail; }
+  else if (L >= nmain) t = L - nmain;
+  if (t < 0) {
+    // (tail_first with ntail % 8 != 0: id L runs on XCD (L + ntail) % 8 -- still one XCD per value of L % 8)
     const int full = (ngroups & ~7) * gx;      // ids covered by whole octets of groups
-    int g, t;
-    if (L < full) { const int slot = L >> 3; g = ((slot / gx) << 3) + (L & 7); t = slot % gx; }
-    else { const int r = L - full; g = (ngroups & ~7) + r / gx; t = r % gx; }
-    bx = t; by = g % gy; bz = g / gy;
+    int g, tl;
+    if (L < full) { const int slot = L >> 3; g = ((slot / gx) << 3) + (L & 7); tl = slot % gx; }
+    else { const int r = L - full; g = (ngroups & ~7) + r / gx; tl = r % gx; }
+    bx = tl; by = g % gy; bz = g / gy;
     return -1;
   }
-  const int t = L - nmain;
   bx = 0; by = (t / tail_slots) % gy; bz = t / (tail_slots * gy);
   return t % tail_slots;
 }
@@ -804,12 +814,13 @@ __global__ __launch_bounds__(256, 2) void attn_ks_kernel(const float* Q, const f
 // each wave stages its own K / V tiles in its own LDS region and the tile loop has NO workgroup barrier; the four partial
 // (m, l, O) states meet once, at the end.  Dynamic LDS (4 x 2 tiles x 8448 B = 66 KiB, over the static limit).
 // ---------------------------------------------------------------------------------------------
-constexpr int ATK4_LDS_FLOATS = 4 * 2 * 64 * AT_STRIDE + LG_TAIL_MAX * 128;
-__global__ __launch_bounds__(256, 2) void attn_k4_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
+template <int NKQ> constexpr int atk4_lds_floats() { return NKQ * 2 * 64 * AT_STRIDE + LG_TAIL_MAX * 128; }
+template <int NKQ>   // key parts = waves per workgroup: 4, or 8 (two waves per SIMD, half the serial length again)
+__global__ __launch_bounds__(64 * NKQ) void attn_k4_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
                                                          const LgSet* sets, int tail_slots, int cross, float scale) {
   extern __shared__ __attribute__((aligned(16))) float k4_lds[];
   float* sKV = k4_lds;                                      // [key quarter][K | V][64 d][33]
-  float* sTK = k4_lds + 4 * 2 * 64 * AT_STRIDE;
+  float* sTK = k4_lds + NKQ * 2 * 64 * AT_STRIDE;
   int bx, head, bz;
   const int tail_q = attn_role(tail_slots, bx, head, bz);
   const LgSet st = sets[bz];
@@ -841,7 +852,7 @@ __global__ __launch_bounds__(256, 2) void attn_k4_kernel(const float* Q, const f
   for (int r = 0; r < 16; r++) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
   float m = -1e30f, l = 0.0f;
 
-  const int ntiles = (k_n + 31) / 32, quarter = (ntiles + 3) / 4;
+  const int ntiles = (k_n + 31) / 32, quarter = (ntiles + NKQ - 1) / NKQ;
   const int kt0 = kq * quarter, kt1 = min(kt0 + quarter, ntiles);
   // this wave's staging of one key tile: K and V, 64 d x 32 keys each = 512 float4 per matrix, 8 + 8 per lane
   f32x4 pk[8], pv[8];
@@ -896,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void attn_k4_kernel(const float* Q, const f
     attn_pv_tile(sV, s, o, j, h);
   }
 #undef ATK4_PREFETCH
-  if (ntail > 0 && kq == 3) attn_tail_keys(sTK, ntail, qreg, o, m, l, h);   // the last quarter is the shortest
+  if (ntail > 0 && kq == NKQ - 1) attn_tail_keys(sTK, ntail, qreg, o, m, l, h);   // the last quarter is the shortest
   // ---- merge: quarters 1..3 leave their state in their OWN tile region (64 lanes x 34 floats), quarter 0 folds them in
   if (kq != 0) {
     float* p = sK + lane * 34;
@@ -907,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void attn_k4_kernel(const float* Q, const f
   __syncthreads();
   if (kq == 0) {
 #pragma unroll
-    for (int w = 1; w < 4; w++) {
+    for (int w = 1; w < NKQ; w++) {
       const float* p = sKV + (size_t)w * 2 * 64 * AT_STRIDE + lane * 34;
       const float m1 = p[0], l1 = p[1];
       const float mm = fmaxf(m, m1);
@@ -1334,9 +1345,19 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   // fewer key-split workgroups than CUs (one pair of 1024 keypoints: 136): four key quarters per 32-query block instead
   else if (g_attn_force == 5 || (g_attn_force == 0 && ((max_mp + 63) / 64) * 4 * nsets <= 256)) {
-    static bool attr_set = false;   // idempotent; a race between two first callers sets the same value twice
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_k4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATK4_LDS_FLOATS * 4); attr_set = true; }
-    hipLaunchKernelGGL(attn_k4_kernel, dim3((max_mp + 31) / 32 + max_tail, 4, nsets), dim3(256), (size_t)ATK4_LDS_FLOATS * 4, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+    static bool attr_set = false;   // idempotent; a race between two first callers sets the same values twice
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)attn_k4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, atk4_lds_floats<4>() * 4);
+      (void)hipFuncSetAttribute((const void*)attn_k4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, atk4_lds_floats<8>() * 4);
+      attr_set = true;
+    }
+    static const int parts = getenv("DANI_ATTN_K4_PARTS") ? atoi(getenv("DANI_ATTN_K4_PARTS")) : 4;
+    static const int tail_sign = getenv("DANI_ATTN_K4_TAIL_LAST") ? 1 : -1;
+    const int k4_tail = tail_sign * max_tail;
+    if (parts == 8 && max_mp >= 8 * 32 * 2)   // at least two key tiles per part
+      hipLaunchKernelGGL(attn_k4_kernel<8>, dim3((max_mp + 31) / 32 + max_tail, 4, nsets), dim3(512), (size_t)atk4_lds_floats<8>() * 4, s, Q, K, V, O, ld, sets, k4_tail, cross, scale);
+    else
+      hipLaunchKernelGGL(attn_k4_kernel<4>, dim3((max_mp + 31) / 32 + max_tail, 4, nsets), dim3(256), (size_t)atk4_lds_floats<4>() * 4, s, Q, K, V, O, ld, sets, k4_tail, cross, scale);
   } else
     hipLaunchKernelGGL(attn_ks_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
 }
