@@ -200,7 +200,7 @@ def main():
 
     import threading
     NSEQ = max(1, args.sequences) if cfg == 4 else 1
-    PROF_EVERY = 10
+    PROF_EVERY = 20
     # N > 1: the batch is ONE sequence of consecutive frames sharded over the ranks (BASELINE config #4), so the pair
     # (last frame of rank r-1, first frame of rank r) crosses a GPU boundary: extract -> all-gather of every rank's last
     # frame (features packed on the device, one RCCL all_gather_into_tensor over xGMI) -> LightGlue with that predecessor
@@ -286,6 +286,9 @@ def main():
     # settle phase (untimed, part of set-up): first touches of every workspace, clocks and the host worker pool reach steady
     # state; a process that starts right after another one released the GPU sees a few slow steps
     run_steps(30, False)
+    if cfg == 4:   # one profiled step outside the timed region: the engine creates its ~170 timing events on first use (7 ms)
+        for q in range(NSEQ):
+            eng.set_profiling(True); call(cfg, q); eng.set_profiling(False)
     run_steps(max(args.warmup, NSEQ), False)
     # like timeit: no cyclic-GC pass inside the timed region (a generation-2 collection over the weight / frame objects
     # of this process takes 35-50 ms, four steps' worth, and lands ~0.7 s after start-up)
