@@ -251,7 +251,7 @@ def main():
             try:
                 for it in range(total // NSEQ + (1 if seq < total % NSEQ else 0)):
                     # per-kernel HIP-event timing costs ~0.4 ms per step (166 events): sample every PROF_EVERY-th step
-                    sample = collect and mode == 4 and it % PROF_EVERY == 0
+                    sample = collect and mode == 4 and it % PROF_EVERY == min(PROF_EVERY, total // NSEQ) // 2
                     if collect:
                         eng.set_profiling(sample)
                     ts = time.perf_counter()
@@ -289,12 +289,13 @@ def main():
     if cfg == 4:   # one profiled step outside the timed region: the engine creates its ~170 timing events on first use (7 ms)
         for q in range(NSEQ):
             eng.set_profiling(True); call(cfg, q); eng.set_profiling(False)
-    run_steps(max(args.warmup, NSEQ), False)
     # like timeit: no cyclic-GC pass inside the timed region (a generation-2 collection over the weight / frame objects
-    # of this process takes 35-50 ms, four steps' worth, and lands ~0.7 s after start-up)
+    # of this process takes 35-50 ms, four steps' worth, and lands ~0.7 s after start-up).  Collected BEFORE the warm-up
+    # steps: the GPU idles while the collector runs and the first step after such a pause is ~2 ms slow (clocks).
     import gc
     gc.collect()
     gc.disable()
+    run_steps(max(args.warmup, NSEQ), False)
     barrier()
     t0 = time.perf_counter()
     outs, layer_ms, fe_ms, attn, lin, step_ms = run_steps(args.steps, True)
@@ -367,7 +368,8 @@ def main():
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.lg_gemm == "f32" else f"f32 (LightGlue matrix products: {args.lg_gemm} operand split on the bf16 MFMA, f32 accumulate)", "data": "synthetic" + (" (frames handed over as HOST buffers: PCIe-inclusive)" if args.host_inputs else ""),
             "step_ms": {"median": pct(step_ms, 50), "p10": pct(step_ms, 10), "p90": pct(step_ms, 90), "min": pct(step_ms, 0), "max": pct(step_ms, 100),
-                        "n": len(step_ms), "what": "wall time of every dani_frontend_batch call of the timed region on rank 0 (all sequences)"},
+                        "n": len(step_ms), "what": "wall time of every dani_frontend_batch call of the timed region on rank 0 (all sequences)",
+                        "slow_steps": [[i, round(x, 2)] for i, x in enumerate(step_ms) if x > pct(step_ms, 50) + 0.3][:24]},
         }
         if cfg == 4:
             conv_dom_ms = float(sum(layer_ms[i] for i in DOMINANT_LAYERS))
