@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--no-boundary-exchange", action="store_true",
                     help="N > 1: treat every rank's frames as a sequence of its own instead of exchanging the shard-boundary frame "
                          "(rank r's first frame is then matched against rank r's own last frame of the previous step)")
+    ap.add_argument("--force-boundary-exchange", action="store_true",
+                    help="N = 1 only: take the N > 1 code path (extract, export of the last frame's features on the device, "
+                         "match against the carried slab) to price the split call on one GPU")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra bf16x3 / batch-1 measurements (profiling runs)")
     args = ap.parse_args()
 
@@ -204,7 +207,7 @@ def main():
     # N > 1: the batch is ONE sequence of consecutive frames sharded over the ranks (BASELINE config #4), so the pair
     # (last frame of rank r-1, first frame of rank r) crosses a GPU boundary: extract -> all-gather of every rank's last
     # frame (features packed on the device, one RCCL all_gather_into_tensor over xGMI) -> LightGlue with that predecessor
-    boundary = cfg == 4 and world > 1 and NSEQ == 1 and not args.no_boundary_exchange
+    boundary = cfg == 4 and (world > 1 or args.force_boundary_exchange) and NSEQ == 1 and not args.no_boundary_exchange
     CAP = NFEATURES + 12
     carry = {"slab": None}      # rank 0: the last rank's final frame of the previous step
 
@@ -217,7 +220,7 @@ def main():
         elif mode == 3:
             kw.update(use_yolo=False, stereo_pairs=True)
         if mode == 4 and boundary:
-            kw.update(match_previous=False)
+            kw.update(match_previous=False, defer_desc=True)   # descriptors reach the host under the LightGlue of match_resident
         if args.host_inputs:
             out_ = eng.frontend_batch(frames[:nb], frames_bgr[:nb] if mode == 4 else None, **kw)
         else:

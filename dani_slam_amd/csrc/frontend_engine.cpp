@@ -23,7 +23,21 @@ struct SeqState {
   // resident features of the last dani_frontend_batch call (for dani_frontend_export_features / _match_resident)
   int res_B = 0, res_W = 0, res_H = 0;
   std::vector<int32_t> res_n;
+  // descriptor read-back left running by a defer_desc call: stream2 is filling the pinned staging, `pend_desc` is the caller's array
+  float* pend_desc = nullptr;
+  int pend_cap = 0;
 };
+// finish a deferred descriptor read-back (wait for the staging copy, move it into the caller's array); S->mu is held
+void finish_pending_desc(SeqState* S) {
+  if (!S->pend_desc || !S->ctx) { S->pend_desc = nullptr; return; }
+  Context* c = S->ctx;
+  float* desc = S->pend_desc; const int cap = S->pend_cap, B = S->res_B;
+  S->pend_desc = nullptr;
+  if (hipStreamSynchronize(c->stream2) != hipSuccess) return;
+  host_pool().run(B, [&](int b) {
+    if (S->res_n[b]) memcpy(desc + (size_t)b * cap * 256, c->h_desc + (size_t)b * c->kcap * 256, (size_t)S->res_n[b] * 1024);
+  });
+}
 // one SeqState (context + cached previous frame) per (engine, sequence id); id 0 also holds the class lists
 SeqState* seq_state(dani_engine* e, int id = 0) {
   std::lock_guard<std::mutex> lk(e->mu);
@@ -60,6 +74,7 @@ int dani_frontend_reset(dani_engine* e, int32_t sequence) {
   if (!e) return DANI_ERR_INVALID;
   SeqState* S = seq_state(e, sequence);
   std::lock_guard<std::mutex> lk(S->mu);
+  finish_pending_desc(S);
   if (S->ctx) S->ctx->prev_n = 0;
   return DANI_OK;
 }
@@ -90,6 +105,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   SeqState* S0 = seq_state(e, 0);
   SeqState* S = seq_state(e, sequence);
   std::lock_guard<std::mutex> seq_lock(S->mu);
+  finish_pending_desc(S);   // a defer_desc call that was never followed by dani_frontend_match_resident
   std::vector<std::string> class_names, dynamic_names;
   if (p->use_yolo) {
     if (S != S0) { std::lock_guard<std::mutex> lk0(S0->mu); class_names = S0->class_names; dynamic_names = S0->dynamic_names; }
@@ -253,13 +269,16 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     }
   }
   const bool synced = cache_enqueued;   // LightGlue ran: its final synchronise covered the cache copies
+  const bool defer = p->defer_desc && !p->match_previous && desc;   // split form: dani_frontend_match_resident finishes the read-back
+  if (defer) { enqueue_cache(); desc_moved = true; }
   move_desc();
   if (!synced) HIP_TRY(e, hipStreamSynchronize(c->stream));
-  HIP_TRY(e, hipStreamSynchronize(c->stream2));
+  if (!defer) HIP_TRY(e, hipStreamSynchronize(c->stream2));
   HIP_TRY(e, hipGetLastError());
   if (e->profiling) sp_read_timers(c, true);
   if (p->match_previous) c->prev_n = stereo ? 0 : n_out[B - 1];   // an extract-only call leaves the predecessor to dani_frontend_match_resident
   S->res_B = B; S->res_W = W; S->res_H = H; S->res_n.assign(n_out, n_out + B);
+  if (defer) { S->pend_desc = desc; S->pend_cap = cap; }
   S->ms[2] = ms_since(t2);
   S->ms[3] = ms_since(t0);
   return DANI_OK;
@@ -316,12 +335,15 @@ int dani_frontend_match_resident(dani_engine* e, int32_t sequence, const float* 
   const float sz[2] = {(float)S->res_W, (float)S->res_H};
   LgCall lg_call;
   lg_call.ctx = c;
+  std::function<void()> finish_desc = [&] { finish_pending_desc(S); };   // a deferred descriptor read-back ends under the forward pass
+  lg_call.overlap = &finish_desc;
   int rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kimg_all, c->d_desc_all, n0.data(), c->d_kimg, c->d_descout, n1.data(), sz, sz,
                          lg_threshold, matches, scores, match_cap, k_out);
+  finish_pending_desc(S);
   if (rc) return rc;
   HIP_TRY(e, hipMemcpyAsync(c->d_kimg_all, c->d_kimg + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(e, hipStreamSynchronize(c->stream));
+  // no host wait: every later use of the cache slabs is enqueued on this same stream
   c->prev_n = S->res_n[B - 1];
   return DANI_OK;
 }

@@ -51,7 +51,7 @@ class _SpParams(C.Structure):
 
 _FrontendParams._fields_ = [("sp", _SpParams), ("use_yolo", C.c_int32), ("yolo_score_thresh", C.c_float),
                             ("yolo_iou_thresh", C.c_float), ("match_previous", C.c_int32), ("lg_threshold", C.c_float),
-                            ("lapping", C.c_int32 * 2), ("pair_mode", C.c_int32)]
+                            ("lapping", C.c_int32 * 2), ("pair_mode", C.c_int32), ("defer_desc", C.c_int32)]
 
 _lib = None
 
@@ -448,12 +448,14 @@ class Engine:
 
     def frontend_batch(self, gray, bgr=None, nfeatures=1024, iniTh=0.015, minTh=0.007, use_yolo=True, match_previous=True,
                        lg_threshold=0.05, lapping=(0, 0), want_desc=True, device_ptrs=None, shape=None, box_cap=512, copy=True,
-                       sequence=0, scaleFactor=1.2, nlevels=1, stereo_pairs=False):
+                       sequence=0, scaleFactor=1.2, nlevels=1, stereo_pairs=False, defer_desc=False):
         """gray [B,H,W] u8 and bgr [B,H,W,3] u8 host arrays, or device_ptrs=(gray_ptr, bgr_ptr) + shape=(B,H,W).
         Returns a list of per-frame dicts: kpts, resp, desc (or None), mono_index, boxes [k,4], matches [K,2], scores.
         copy=False returns views into buffers that the next call overwrites.
         stereo_pairs: frames (2k, 2k+1) are left / right images; frame 2k+1 carries the left-vs-right matches
         (dani_frontend_params.pair_mode = 1, Frame::ComputeStereoMatches)."""
+        if defer_desc and copy:
+            raise ValueError("defer_desc needs copy=False: the descriptor rows are complete only after frontend_match_resident")
         if device_ptrs is None:
             gray = np.ascontiguousarray(gray, np.uint8)
             B, H, W = gray.shape
@@ -476,6 +478,9 @@ class Engine:
         p.match_previous = int(match_previous); p.lg_threshold = lg_threshold
         p.lapping[0], p.lapping[1] = int(lapping[0]), int(lapping[1])
         p.pair_mode = 1 if stereo_pairs else 0
+        # split form (match_previous=False, then frontend_match_resident): the descriptor rows of the returned views are
+        # complete only after frontend_match_resident / frontend_reset / the next frontend_batch of the sequence
+        p.defer_desc = 1 if (defer_desc and not match_previous) else 0
         if not hasattr(self, "_fe_bufs_by_seq"):
             self._fe_bufs_by_seq = {}
         bufs = self._fe_bufs_by_seq.get(sequence)

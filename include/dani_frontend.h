@@ -249,6 +249,11 @@ typedef struct dani_frontend_params {
                               Frame::ComputeStereoMatches, src/Frame.cc:124-143, :813-860); B must be even, nothing is
                               cached across calls; matches / scores / k_out of pair k are delivered in the slots of frame
                               2k+1 as (index in left, index in right), the slots of frame 2k report k_out = 0 */
+  int32_t defer_desc;      /* split form only (match_previous = 0 followed by dani_frontend_match_resident, the N > 1 sharding of
+                              BASELINE config #4): 1 = the call returns as soon as keypoints and counts are on the host; the
+                              descriptor read-back into `desc` keeps running and is completed by dani_frontend_match_resident
+                              (under its LightGlue pass), by dani_frontend_reset or by the next dani_frontend_batch of the
+                              sequence.  `desc` must stay valid and unread until then.  0 = `desc` is complete on return */
 } dani_frontend_params;
 
 /* `sequence` selects one of any number of independent image sequences (cameras): each has its own stream, workspace

@@ -209,4 +209,18 @@ def test_split_form_equals_fused_call_and_takes_a_foreign_predecessor(sp_weights
     got = d_out.cpu().numpy()
     assert n == int(ref7[0]) and np.array_equal(got[:1 + 2 * n], ref7[:1 + 2 * n])
     assert np.array_equal(got[1 + 2 * cap:1 + 2 * cap + 256 * n], ref7[1 + 2 * cap:1 + 2 * cap + 256 * n])
+    # defer_desc: the extract call returns before the descriptors have reached the host; match_resident (under its LightGlue
+    # pass), frontend_reset or the next call of the sequence complete them.  Same rows, same matches.
+    e.frontend_reset()
+    e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False)
+    e.frontend_match_resident(4, cap=cap)
+    xd = e.frontend_batch(gray[4:], bgr[4:], nfeatures=NF, match_previous=False, defer_desc=True, copy=False)
+    md = e.frontend_match_resident(4, cap=cap)
+    assert all(same(m, f) for m, f in zip(md, fused[4:]))
+    assert all(np.array_equal(a["desc"], b["desc"]) and np.array_equal(a["kpts"], b["kpts"]) for a, b in zip(xd, fused[4:]))
+    xd = e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False, defer_desc=True, copy=False)
+    e.frontend_reset()                                               # never matched: reset completes the read-back
+    assert all(np.array_equal(a["desc"], b["desc"]) for a, b in zip(xd, fused[:4]))
+    with pytest.raises(ValueError):
+        e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False, defer_desc=True)   # copy=True would copy unfinished rows
     e.close()
