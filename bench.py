@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--no-boundary-exchange", action="store_true",
                     help="N > 1: treat every rank's frames as a sequence of its own instead of exchanging the shard-boundary frame "
                          "(rank r's first frame is then matched against rank r's own last frame of the previous step)")
+    ap.add_argument("--no-pipelined-exchange", action="store_true",
+                    help="N > 1: lock-step form (extract, all-gather, match inside one step) instead of matching step t behind "
+                         "the extraction of step t + 1")
     ap.add_argument("--force-boundary-exchange", action="store_true",
                     help="N = 1 only: take the N > 1 code path (extract, export of the last frame's features on the device, "
                          "match against the carried slab) to price the split call on one GPU")
@@ -210,6 +213,12 @@ def main():
     boundary = cfg == 4 and (world > 1 or args.force_boundary_exchange) and NSEQ == 1 and not args.no_boundary_exchange
     CAP = NFEATURES + 12
     carry = {"slab": None}      # rank 0: the last rank's final frame of the previous step
+    # N > 1: the LightGlue of step t runs behind the extraction of step t + 1 (two engine sequences, ping-pong), with the
+    # all-gather of step t's boundary features posted in between: one extraction of slack, so that a rank that is a few
+    # milliseconds late in one step does not stall the others (lock-step, every step costs the MAX over ranks).
+    pipelined = boundary and not args.no_pipelined_exchange
+    pend = {"job": None, "step": 0}
+    xchg = None
 
     def call(mode, seq=0, nb=None):
         """mode 4: full front-end; 2: SuperPoint extract only; 3: SuperPoint x 2 + LightGlue of the (left, right) pair."""
@@ -219,6 +228,8 @@ def main():
             kw.update(use_yolo=False, match_previous=False)
         elif mode == 3:
             kw.update(use_yolo=False, stereo_pairs=True)
+        if mode == 4 and pipelined:
+            return call_pipelined(kw, nb)
         if mode == 4 and boundary:
             kw.update(match_previous=False, defer_desc=True)   # descriptors reach the host under the LightGlue of match_resident
         if args.host_inputs:
@@ -226,20 +237,49 @@ def main():
         else:
             out_ = eng.frontend_batch(None, None, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()), shape=(nb, H, W), **kw)
         if mode == 4 and boundary:
-            slabs = sharding.exchange_boundary_features(eng, nb - 1, CAP, reduce_dev, seq)
-            pred = slabs[rank - 1] if rank > 0 else carry["slab"]
-            if pred is None:
-                eng.frontend_reset(seq)
-                res_ = eng.frontend_match_resident(nb, cap=CAP, sequence=seq)
-            elif pred.is_cuda:
-                res_ = eng.frontend_match_resident(nb, pred_device_ptr=pred.data_ptr(), pred_cap=CAP, cap=CAP, sequence=seq)
-            else:
-                res_ = eng.frontend_match_resident(nb, pred=pred.numpy(), cap=CAP, sequence=seq)
-            if rank == 0:
-                carry["slab"] = slabs[world - 1].clone()
-            for o_, (m_, s_) in zip(out_, res_):
-                o_["matches"], o_["scores"] = m_, s_
+            match_boundary(out_, sharding.exchange_boundary_features(eng, nb - 1, CAP, reduce_dev, seq), nb, seq)
         return out_
+
+    def match_boundary(out_, slabs, nb, seq):
+        pred = slabs[rank - 1] if rank > 0 else carry["slab"]
+        if pred is None:
+            eng.frontend_reset(seq)
+            res_ = eng.frontend_match_resident(nb, cap=CAP, sequence=seq)
+        elif pred.is_cuda:
+            res_ = eng.frontend_match_resident(nb, pred_device_ptr=pred.data_ptr(), pred_cap=CAP, cap=CAP, sequence=seq)
+        else:
+            res_ = eng.frontend_match_resident(nb, pred=pred.numpy(), cap=CAP, sequence=seq)
+        if rank == 0:
+            carry["slab"] = slabs[world - 1].clone()
+        for o_, (m_, s_) in zip(out_, res_):
+            o_["matches"], o_["scores"] = m_, s_
+        return out_
+
+    def finish_pending():
+        job = pend["job"]
+        if job is None:
+            return None
+        pend["job"] = None
+        out_, ticket, nb_, seq_ = job
+        return match_boundary(out_, xchg.wait(ticket), nb_, seq_)
+
+    def call_pipelined(kw, nb):
+        nonlocal xchg
+        if xchg is None:
+            xchg = sharding.BoundaryExchange(eng, CAP, reduce_dev)
+        seq = pend["step"] & 1
+        pend["step"] += 1
+        kw = dict(kw, match_previous=False, defer_desc=True, sequence=seq)
+        if args.host_inputs:
+            out_ = eng.frontend_batch(frames[:nb], frames_bgr[:nb], **kw)
+        else:
+            out_ = eng.frontend_batch(None, None, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()), shape=(nb, H, W), **kw)
+        if pend.get("sample"):                    # SuperPoint's layer timers belong to THIS extraction's context: read them now
+            pend["lt"], pend["ft"] = eng.layer_timings(), eng.frontend_timings()
+        ticket = xchg.start(nb - 1, seq)
+        done = finish_pending()                  # LightGlue of the PREVIOUS step, whose all-gather was posted one extraction ago
+        pend["job"] = (out_, ticket, nb, seq)
+        return done if done is not None else out_
 
     def run_steps(total, collect, mode=cfg, nb=None):
         """`total` steps dealt round-robin to NSEQ concurrent sequences (one host thread each).  Returns the last outputs,
@@ -257,19 +297,27 @@ def main():
                     sample = collect and mode == 4 and it % PROF_EVERY == min(PROF_EVERY, total // NSEQ) // 2
                     if collect:
                         eng.set_profiling(sample)
+                    pend["sample"] = sample
                     ts = time.perf_counter()
                     outs[seq] = call(mode, seq, nb)
                     step_ms[seq].append((time.perf_counter() - ts) * 1e3)
                     if sample:
                         nsamp[seq] += 1
-                        acc[seq][0][:] += eng.layer_timings()
-                        acc[seq][1][:] += eng.frontend_timings()
+                        acc[seq][0][:] += pend["lt"] if (pipelined and mode == 4) else eng.layer_timings()
+                        acc[seq][1][:] += pend["ft"] if (pipelined and mode == 4) else eng.frontend_timings()
                         acc[seq][2][:] += np.array(eng.lg_attention_profile(), np.float64)
                         acc[seq][3][:] += np.array(eng.lg_linear_profile(), np.float64)
             except Exception as ex:   # surface worker failures in the main thread
                 errs.append(ex)
         if NSEQ == 1:
             worker(0)
+            if mode == 4 and pipelined:          # the last step's LightGlue belongs to this region
+                ts = time.perf_counter()
+                last = finish_pending()
+                if last is not None:
+                    outs[0] = last
+                    if step_ms[0]:
+                        step_ms[0][-1] += (time.perf_counter() - ts) * 1e3
         else:
             th = [threading.Thread(target=worker, args=(q,)) for q in range(NSEQ)]
             for t_ in th: t_.start()
@@ -404,7 +452,9 @@ def main():
                              "note_matches": "frame 0 of a step is matched against frame B-1 of the previous step (the same 8 frames "
                                              "are replayed every step): a 14-degree jump, few matches; frames 1..B-1 are consecutive",
                              "parallelism": (f"frame-sharded x{world}; one all-gather of every rank's last-frame features per step (1 MB per rank, "
-                                             "device buffers) for the pair that crosses a shard boundary" if boundary else
+                                             "device buffers) for the pair that crosses a shard boundary"
+                                             + ("; posted after a step's extraction and waited for one extraction later: the LightGlue of "
+                                                "step t runs behind the extraction of step t + 1" if pipelined else "; lock-step") if boundary else
                                              f"frame-sharded x{world}, no data-path collective")}
             res["roofline"] = {"bound": "mfma", "kernel": "linear_fm_kernel<64> (LightGlue feature-major linear layers: 6 per layer x 9 + final_proj)",
                                "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -86,3 +86,42 @@ def exchange_boundary_features(eng, last_frame: int, cap: int, device=None, sequ
         # (non-blocking) HIP stream, so the gathered bytes must have landed before the pointer is handed over
         torch.cuda.current_stream(mine.device).synchronize()
     return out.reshape(world, nfl)
+
+
+class BoundaryExchange:
+    """exchange_boundary_features split into start() and wait(): the all-gather is posted right after a rank's extraction and
+    waited for one extraction later (bench.py's N > 1 loop runs the LightGlue of step t behind the extraction of step t + 1, on
+    a second engine sequence), so that a rank that was late by a few milliseconds in one step does not stall the other N - 1 --
+    every step of the lock-step form costs the group the MAXIMUM of the ranks' step times."""
+
+    def __init__(self, eng, cap: int, device=None):
+        import torch.distributed as dist
+        self.eng, self.cap, self.device = eng, cap, device
+        self.nfl = eng.feature_slab_floats(cap)
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.on_gpu = device is not None and (not dist.is_initialized() or dist.get_backend() == "nccl")
+
+    def start(self, last_frame: int, sequence: int = 0):
+        """Pack this rank's boundary frame (on the device for nccl) and post the collective.  Returns a ticket for wait()."""
+        import torch
+        import torch.distributed as dist
+        if self.on_gpu:
+            mine = torch.empty(self.nfl, dtype=torch.float32, device=self.device)
+            self.eng.frontend_export_features(last_frame, self.cap, sequence, device_ptr=mine.data_ptr())
+        else:
+            mine = torch.from_numpy(self.eng.frontend_export_features(last_frame, self.cap, sequence))
+        if self.world == 1:
+            return (None, mine.reshape(1, self.nfl), mine)
+        out = torch.empty(self.world * self.nfl, dtype=torch.float32, device=mine.device)
+        work = dist.all_gather_into_tensor(out, mine, async_op=True)
+        return (work, out.reshape(self.world, self.nfl), mine)      # `mine` is kept alive until the collective has read it
+
+    def wait(self, ticket):
+        """The gathered [world, slab] tensor, complete (the engine reads it from its own stream)."""
+        import torch
+        work, out, _mine = ticket
+        if work is not None:
+            work.wait()
+            if self.on_gpu:
+                torch.cuda.current_stream(out.device).synchronize()
+        return out

@@ -58,6 +58,12 @@ def _worker(rank, world, port, q):
             row = slabs[rr].numpy()
             ok = ok and int(row[0]) == nn and np.array_equal(row[1:1 + 2 * nn].reshape(nn, 2), ek)
             ok = ok and np.array_equal(row[1 + 32:1 + 32 + 256 * nn].reshape(nn, 256), ed)
+        # the asynchronous form bench.py uses by default: two collectives posted back to back, waited for in order
+        x = sharding.BoundaryExchange(FakeEngine(), 16, None)
+        t0 = x.start(7, 0); t1 = x.start(7, 1)
+        for t in (t0, t1):
+            again = x.wait(t)
+            ok = ok and tuple(again.shape) == (world, 1 + 16 * 258) and bool((again == slabs).all())
         mx = sharding.reduce_max_seconds(1.0 + rank)
         frames = list(sharding.shard_frames(16, rank, world))
         q.put((rank, ok, mx, frames))
