@@ -1345,7 +1345,10 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   // fewer key-split workgroups than CUs (one pair of 1024 keypoints: 136): four key quarters per 32-query block instead
   else if (g_attn_force == 5 || (g_attn_force == 0 && ((max_mp + 63) / 64) * 4 * nsets <= 256)) {
-    static bool attr_set = false;   // idempotent; a race between two first callers sets the same values twice
+    static bool attr_set_dev[64] = {};   // per device; idempotent: a race between two first callers sets the same values twice
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_set_dev[dev_ & 63];
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)attn_k4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, atk4_lds_floats<4>() * 4);
       (void)hipFuncSetAttribute((const void*)attn_k4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, atk4_lds_floats<8>() * 4);
