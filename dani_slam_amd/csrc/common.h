@@ -48,7 +48,22 @@ enum ConvVariant {
   // 4 x 32-pixel x 32-cout workgroups (one image row per wave) for the 12 x 20 level of YOLOv5s: three tiles cover a
   // frame's 240 pixels at 62 % (the 8 x 16 tiles need four, 47 %)
   CONV3_R4_SILU = 19, CONV3S2_R4_SILU = 20, CONV1_R4_SILU = 21, CONV1_R4_LINEAR = 22,
+  // K-segmented twins (conv_kseg): 2 segments on the 8x16 small tiles (-> 4x16-pixel workgroups), 4 segments on the 4x32
+  // tiles (-> one 32-pixel row per workgroup), 2 segments for the long 1x1 layers
+  CONV3_BLK16S_SILU_K2 = 23, CONV3S2_BLK16S_SILU_K2 = 24, CONV3_R4_SILU_K4 = 25, CONV3S2_R4_SILU_K2 = 26,
+  CONV1_BLK16S_SILU_K2 = 27, CONV1_R4_SILU_K2 = 28, CONV1_R4_LINEAR_K2 = 29,
 };
+
+// Canonical K segmentation of a YOLOv5s convolution (conv_mfma.hip, Cfg::SEG; oracle/sp_oracle.cpp orc_conv2d_ex follows the
+// same rule): a function of the layer's shape only.  3x3 stride 1: 4 segments from 256 input channels, 2 from 128; 3x3
+// stride 2: 2 from 128 (four one-row workgroup tiles of a stride-2 layer re-stage three input rows per output row: measured
+// slower than the unsplit kernel); 1x1: 2 from 512.
+inline int conv_kseg(int cin, int k, int stride) {
+  if (k == 3 && stride == 1) return cin >= 256 ? 4 : (cin >= 128 ? 2 : 1);
+  if (k == 3) return cin >= 128 ? 2 : 1;
+  if (k == 1) return cin >= 512 ? 2 : 1;
+  return 1;
+}
 
 // tensor views for one conv launch: tensors may be channel slices of larger (concat) buffers
 struct ConvIO {
@@ -74,7 +89,15 @@ void pack_conv_weights(const float* w_oihw, const float* bias, int Cin, int Cout
                        float* w_packed, float* bias_packed);
 inline int conv_variant_cc(ConvVariant v) {
   return (v == CONV1_BLK16_LINEAR || v == CONV1_ROW32_SILU || v == CONV1_BLK16_SILU || v == CONV1_BLK16S_LINEAR ||
-          v == CONV1_BLK16S_SILU || v == CONV1_ROW32N_SILU || v == CONV1_R4_SILU || v == CONV1_R4_LINEAR) ? 32 : ((v == CONV6S2_ROW32_SILU || v == CONV6S2_ROW32N_SILU) ? 4 : 8);
+          v == CONV1_BLK16S_SILU || v == CONV1_ROW32N_SILU || v == CONV1_R4_SILU || v == CONV1_R4_LINEAR ||
+          v == CONV1_BLK16S_SILU_K2 || v == CONV1_R4_SILU_K2 || v == CONV1_R4_LINEAR_K2) ? 32 : ((v == CONV6S2_ROW32_SILU || v == CONV6S2_ROW32N_SILU) ? 4 : 8);
+}
+inline int conv_variant_kseg(ConvVariant v) {
+  switch (v) {
+    case CONV3_BLK16S_SILU_K2: case CONV3S2_BLK16S_SILU_K2: case CONV3S2_R4_SILU_K2: case CONV1_BLK16S_SILU_K2: case CONV1_R4_SILU_K2: case CONV1_R4_LINEAR_K2: return 2;
+    case CONV3_R4_SILU_K4: return 4;
+    default: return 1;
+  }
 }
 inline int conv_variant_nco(ConvVariant v) { return v >= CONV3_BLK16S_RELU ? 32 : 64; }   // couts per workgroup
 // the small-grid twin of a 16x16-tile variant (or the variant itself)

@@ -9,8 +9,9 @@
 // One v_mfma_f32_32x32x2_f32 therefore consumes input channels (2cp, 2cp+1) of one filter tap.  The
 // instruction is bit-for-bit an ordered fmaf chain (tools/probes/mfma_chain_probe.hip), so walking k in
 // the order (cp, ky, kx, cc) with the accumulator initialised to the bias reproduces the repo's canonical
-// f32 evaluation order exactly (oracle/sp_oracle.cpp orc_conv2d).  No split-K, no
-// re-association anywhere: the output is bit-identical to the oracle.
+// f32 evaluation order exactly (oracle/sp_oracle.cpp orc_conv2d).  Nothing is re-associated behind
+// the specification's back: where a YOLOv5s layer's order is specified as a sum of K segments (Cfg::SEG, conv_kseg), the
+// segments are separate chains added in the specified order.  The output is bit-identical to the oracle.
 //
 // Work decomposition: a workgroup = 4 waves = 64 couts x (TH x TW) pixels of one frame; each wave owns
 // 2 cout blocks x NPB pixel blocks of 32 pixels (4 independent 32x32 accumulators = 64 VGPRs).  Input
@@ -55,7 +56,13 @@ __device__ int g_conv_launches;
 #define STAMP(i_, v_) do { } while (0)
 #endif
 
-template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2>
+// SEG_: K segments.  The canonical order of a YOLOv5s layer with a long contraction (conv_kseg(), common.h) is a TWO-level sum:
+// the input channels are cut into SEG equal contiguous ranges, each range is accumulated in the usual (channel pair, tap,
+// channel) order -- the bias opens range 0 -- and the range sums are added left to right, ((s0 + s1) + s2) + s3.  A
+// workgroup then gives each range to its own wave(s): 4 / SEG waves along the pixels, SEG along K, every wave a chain
+// 1 / SEG as long, SEG times as many workgroups.  (The deep YOLO levels launch 200-600 workgroups that each walk K = 1152 ...
+// 2304 alone)  SEG = 1: the plain order, everything else in this file.
+template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2, int SEG_ = 1>
 struct Cfg {
   static constexpr int KS = KS_, S = S_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_, ACT = ACT_;
   static constexpr bool POOL = POOL_;
@@ -63,15 +70,20 @@ struct Cfg {
   static constexpr bool HAS_RES = (KS == 3 && S == 1 && ACT == ACT_SILU);   // only YOLOv5's bottleneck cv2 takes a shortcut operand
   static constexpr int PAD = (KS == 1) ? 0 : (KS == 3) ? 1 : 2;   // 1x1 p0, 3x3 p1, 6x6 p2 (YOLOv5 stem)
   static constexpr int NCB = NCB_, NCO = 32 * NCB_;   // cout blocks per wave / couts per workgroup
-  static constexpr int TH = 4 * NPB * PBH, TW = PBW;   // 4 waves stacked vertically (output pixels)
+  static constexpr int SEG = SEG_, WPX = 4 / SEG_;     // K segments / waves along the pixels
+  static constexpr int TH = WPX * NPB * PBH, TW = PBW; // WPX waves stacked vertically (output pixels)
   static constexpr int LROWS = S * (TH - 1) + KS;
   static constexpr int XOFF = (KS == 1) ? 0 : PADX - PAD;          // LDS column of input col (S*px + kx - PAD)
   static constexpr int RS = (XOFF + S * (TW - 1) + KS + 3) / 4 * 4; // LDS row stride (floats), 16-B multiple
   static constexpr int GX0 = (KS == 1) ? PADX : 0;                 // first staged padded column minus S*x0
-  static constexpr int IN_F4 = CC * LROWS * (RS / 4);
-  static constexpr int W_F4 = CC * T * NCO / 4;
-  static constexpr int NI = (IN_F4 + 255) / 256, NW = (W_F4 + 255) / 256;
-  static constexpr int LDS_FLOATS = CC * LROWS * RS + CC * T * NCO;
+  static constexpr int IN_F4 = CC * LROWS * (RS / 4);   // per K segment
+  static constexpr int W_F4 = CC * T * NCO / 4;         // per K segment
+  static constexpr int NI = (SEG * IN_F4 + 255) / 256, NW = (SEG * W_F4 + 255) / 256;   // staging float4 per thread, all segments
+  static constexpr int SEG_IN = CC * LROWS * RS, SEG_W = CC * T * NCO;                  // LDS floats per segment
+  static constexpr int LDS_FLOATS = SEG * (SEG_IN + SEG_W);                             // [seg][input tile] then [seg][weight slab]
+  static_assert(SEG == 1 || SEG == 2 || SEG == 4, "K segments");
+  static_assert(SEG == 1 || !POOL_, "pooled layers are not split");
+  static_assert((SEG - 1) * WPX * 64 * (16 * NCB * NPB + 1) <= LDS_FLOATS, "the segment sums meet in the tile buffers");
   static_assert(PBH * PBW == 32, "a pixel block is one MFMA column block");
   static_assert(!POOL || (PBH == 1 && NPB == 2 && S == 1), "fused pooling needs 2 image rows per wave");
   static_assert(LDS_FLOATS * 4 <= 65536, "LDS budget per workgroup");
@@ -80,8 +92,8 @@ struct Cfg {
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-  float* sIn = lds;
-  float* sW = lds + C::CC * C::LROWS * C::RS;
+  float* sIn = lds;                       // [SEG][CC][LROWS][RS]
+  float* sW = lds + C::SEG * C::SEG_IN;   // [SEG][CC / 2][T][2][NCO]
   // The SiLU instantiations are YOLOv5s layers: a chain of ~60 small dependent launches that runs concurrently with
   // SuperPoint's few huge ones and is the critical path of that phase.  Raise their waves' issue priority so that a
   // YOLO workgroup sharing a SIMD with SuperPoint waves is not slowed to their pace.
@@ -119,27 +131,34 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   const int gy0 = C::S * y0 + a.ipady - C::PAD;
   const int gx0 = C::S * x0 + C::GX0;
   const float* wt = a.w + (size_t)ct * a.nchunks * (C::W_F4 * 4);
+  const int seg_chunks = a.nchunks / C::SEG;                 // chunks per K segment (launch_cfg checks divisibility)
+  const int wpx = wave % C::WPX, seg = wave / C::WPX;        // this wave's pixel sub-tile and K segment
 
-  // per-thread staging offsets (independent of the chunk)
+  // per-thread staging offsets (independent of the chunk): float4 e of the LDS image belongs to segment e / IN_F4
   int goff[C::NI];
 #pragma unroll
   for (int t = 0; t < C::NI; t++) {
     const int e = tid + 256 * t;
-    const int q = e % (C::RS / 4);
-    const int r = (e / (C::RS / 4)) % C::LROWS;
-    const int c = e / ((C::RS / 4) * C::LROWS);
-    goff[t] = (e < C::IN_F4) ? (int)(c * iplane) + (gy0 + r) * a.iWp + gx0 + 4 * q : 0;  // tail lanes re-read element 0
+    const int sg = e / C::IN_F4, el = e % C::IN_F4;
+    const int q = el % (C::RS / 4);
+    const int r = (el / (C::RS / 4)) % C::LROWS;
+    const int c = el / ((C::RS / 4) * C::LROWS) + sg * seg_chunks * C::CC;
+    goff[t] = (e < C::SEG * C::IN_F4) ? (int)(c * iplane) + (gy0 + r) * a.iWp + gx0 + 4 * q : 0;  // tail lanes re-read element 0
   }
   int woff[C::NW];
 #pragma unroll
-  for (int t = 0; t < C::NW; t++) woff[t] = (tid + 256 * t < C::W_F4) ? tid + 256 * t : 0;
+  for (int t = 0; t < C::NW; t++) {
+    const int e = tid + 256 * t;
+    const int sg = e / C::W_F4, el = e % C::W_F4;
+    woff[t] = (e < C::SEG * C::W_F4) ? sg * seg_chunks * C::W_F4 + el : 0;
+  }
 
   f32x16 acc[C::NCB][C::NPB];
 #pragma unroll
   for (int cb = 0; cb < C::NCB; cb++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      const float bv = a.bias[ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+      const float bv = seg ? 0.0f : a.bias[ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];   // the bias opens segment 0
 #pragma unroll
       for (int pb = 0; pb < C::NPB; pb++) acc[cb][pb][r] = bv;
     }
@@ -156,21 +175,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
       pw[t] = wsrc_[woff[t]];                                                                \
   }
 
-  const float* bA = sW + h * C::NCO + j;
-  const float* bB = sIn + (h * C::LROWS + C::S * (wave * C::NPB * C::PBH + j / C::PBW)) * C::RS + C::S * (j % C::PBW) + C::XOFF;
+  const float* bA = sW + seg * C::SEG_W + h * C::NCO + j;
+  const float* bB = sIn + seg * C::SEG_IN + (h * C::LROWS + C::S * (wpx * C::NPB * C::PBH + j / C::PBW)) * C::RS + C::S * (j % C::PBW) + C::XOFF;
 
   DANI_PREFETCH(0);
-  for (int ch = 0; ch < a.nchunks; ch++) {
+  for (int ch = 0; ch < seg_chunks; ch++) {
     __syncthreads();  // everyone finished reading the previous chunk
 #pragma unroll
     for (int t = 0; t < C::NI; t++)
-      if (tid + 256 * t < C::IN_F4) reinterpret_cast<f32x4*>(sIn)[tid + 256 * t] = pin[t];
+      if (tid + 256 * t < C::SEG * C::IN_F4) reinterpret_cast<f32x4*>(sIn)[tid + 256 * t] = pin[t];
 #pragma unroll
     for (int t = 0; t < C::NW; t++)
-      if (tid + 256 * t < C::W_F4) reinterpret_cast<f32x4*>(sW)[tid + 256 * t] = pw[t];
+      if (tid + 256 * t < C::SEG * C::W_F4) reinterpret_cast<f32x4*>(sW)[tid + 256 * t] = pw[t];
     __syncthreads();
     STAMP(3 + 2 * ch, __builtin_readcyclecounter());
-    if (ch + 1 < a.nchunks) DANI_PREFETCH(ch + 1);
+    if (ch + 1 < seg_chunks) DANI_PREFETCH(ch + 1);
 
 #pragma unroll
     for (int cp = 0; cp < C::CC / 2; cp++)
@@ -193,6 +212,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   }
 
 #undef DANI_PREFETCH
+  if constexpr (C::SEG > 1) {
+    // the segment sums meet in LDS (the tile buffers are free after the barrier) and are added left to right by segment 0's waves
+    __syncthreads();
+    constexpr int XS = 16 * C::NCB * C::NPB + 1;
+    if (seg) {
+      float* x = lds + (((seg - 1) * C::WPX + wpx) * 64 + lane) * XS;
+#pragma unroll
+      for (int cb = 0; cb < C::NCB; cb++)
+#pragma unroll
+        for (int pb = 0; pb < C::NPB; pb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) x[(cb * C::NPB + pb) * 16 + r] = acc[cb][pb][r];
+    }
+    __syncthreads();
+    if (seg) return;
+#pragma unroll
+    for (int sg = 1; sg < C::SEG; sg++) {
+      const float* x = lds + (((sg - 1) * C::WPX + wpx) * 64 + lane) * XS;
+#pragma unroll
+      for (int cb = 0; cb < C::NCB; cb++)
+#pragma unroll
+        for (int pb = 0; pb < C::NPB; pb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[cb][pb][r] += x[(cb * C::NPB + pb) * 16 + r];
+    }
+  }
   // ---- epilogue ----
   // Addresses: an accumulator register's output channel is wave-uniform up to the lane half (cu + 4h), so the channel
   // base goes to the scalar unit and the lane adds ONE 32-bit byte offset shared by all 16 x NCB registers.  Written per
@@ -225,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     if (C::HAS_RES && resb) {
 #pragma unroll
       for (int pb = 0; pb < C::NPB; pb++) {
-        const int y = y0 + wave * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
+        const int y = y0 + wpx * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
         const bool ok = y < a.H && x < a.W;
         const unsigned lane_off = 4u * ((unsigned)(y + a.opady) * (unsigned)a.oWp + (unsigned)(x + PADX) + 4u * (unsigned)h * oplane);
 #pragma unroll
@@ -239,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     }
 #pragma unroll
     for (int pb = 0; pb < C::NPB; pb++) {
-      const int y = y0 + wave * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
+      const int y = y0 + wpx * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
       const bool ok = y < a.H && x < a.W;
       const unsigned lane_off = 4u * ((unsigned)(y + a.opady) * (unsigned)a.oWp + (unsigned)(x + PADX) + 4u * (unsigned)h * oplane);
 #pragma unroll
@@ -287,6 +332,14 @@ using CfgR4Silu          = Cfg<3, 1, 1, 32, 1, 8, ACT_SILU, false, 1>;
 using CfgS2R4Silu        = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1>;
 using CfgConv1R4Silu     = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1>;
 using CfgConv1R4         = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1>;
+// K-segmented twins (Cfg::SEG): the long-K layers of YOLO's two deepest levels
+using CfgBlk16sSiluK2    = Cfg<3, 1, 2, 16, 1, 8, ACT_SILU, false, 1, 2>;
+using CfgS2Blk16sSiluK2  = Cfg<3, 2, 2, 16, 1, 8, ACT_SILU, false, 1, 2>;
+using CfgR4SiluK4        = Cfg<3, 1, 1, 32, 1, 8, ACT_SILU, false, 1, 4>;
+using CfgS2R4SiluK2      = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1, 2>;
+using CfgConv1Blk16sSiluK2 = Cfg<1, 1, 2, 16, 1, 32, ACT_SILU, false, 1, 2>;
+using CfgConv1R4SiluK2   = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 2>;
+using CfgConv1R4K2       = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1, 2>;
 
 template <class C>
 static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds) {
@@ -305,6 +358,7 @@ static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   a.tiles_base = a.ntiles / 8; a.tiles_rem = a.ntiles % 8;
   if (a.ntiles <= 0 || a.cout_tiles <= 0) return false;
   if (io.res && !C::HAS_RES) return false;   // this instantiation has no residual path
+  if (a.nchunks % C::SEG) return false;       // K segments are whole chunks
   const int grid = 8 * (a.tiles_base + (a.tiles_rem ? 1 : 0)) * a.cout_tiles;   // 8 XCDs x (largest share of pixel tiles) x cout tiles
   // reserve_lds: dynamic LDS the kernel never touches.  It only lowers how many of THESE workgroups fit on a CU, so that
   // a slot (registers, waves and the rest of the LDS) stays free for the workgroups of a concurrent stream (the fused
@@ -338,6 +392,13 @@ bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV3S2_R4_SILU: return launch_cfg<CfgS2R4Silu>(L, io, B, s, reserve_lds);
     case CONV1_R4_SILU: return launch_cfg<CfgConv1R4Silu>(L, io, B, s, reserve_lds);
     case CONV1_R4_LINEAR: return launch_cfg<CfgConv1R4>(L, io, B, s, reserve_lds);
+    case CONV3_BLK16S_SILU_K2: return launch_cfg<CfgBlk16sSiluK2>(L, io, B, s, reserve_lds);
+    case CONV3S2_BLK16S_SILU_K2: return launch_cfg<CfgS2Blk16sSiluK2>(L, io, B, s, reserve_lds);
+    case CONV3_R4_SILU_K4: return launch_cfg<CfgR4SiluK4>(L, io, B, s, reserve_lds);
+    case CONV3S2_R4_SILU_K2: return launch_cfg<CfgS2R4SiluK2>(L, io, B, s, reserve_lds);
+    case CONV1_BLK16S_SILU_K2: return launch_cfg<CfgConv1Blk16sSiluK2>(L, io, B, s, reserve_lds);
+    case CONV1_R4_SILU_K2: return launch_cfg<CfgConv1R4SiluK2>(L, io, B, s, reserve_lds);
+    case CONV1_R4_LINEAR_K2: return launch_cfg<CfgConv1R4K2>(L, io, B, s, reserve_lds);
   }
   return false;
 }

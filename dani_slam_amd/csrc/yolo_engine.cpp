@@ -108,10 +108,28 @@ int yolo_pack_raw(dani_engine* e, YoloWeights* W, const std::string& name, const
     const int tiles = ((kYH[scale] + 15) / 16) * ((kYW[scale] + 15) / 16);
     if (e->cfg.max_batch * tiles * ((cout + 63) / 64) < 768) L.variant = conv_small_variant(L.variant);
   }
-  if (scale == 4 && !getenv("DANI_YOLO_NO_R4")) {   // 12 x 20: 4 x 32-pixel tiles waste less of every MFMA on padding pixels
+  if (scale == 4) {   // 12 x 20: 4 x 32-pixel tiles waste less of every MFMA on padding pixels
     if (k == 3 && s == 2) L.variant = CONV3S2_R4_SILU;
     else if (k == 3) L.variant = CONV3_R4_SILU;
     else if (k == 1) L.variant = act ? CONV1_R4_SILU : CONV1_R4_LINEAR;
+  }
+  // Long contractions: the canonical order is a sum of K segments (conv_kseg: a function of the layer's shape, the oracle
+  // follows the same rule), each segment on its own wave(s) of a workgroup.  Such layers always take a small-tile variant.
+  const int kseg = conv_kseg(cin, k, s);
+  if (kseg > 1) {
+    L.variant = conv_small_variant(L.variant);
+    switch (L.variant) {
+      case CONV3_BLK16S_SILU: L.variant = kseg == 2 ? CONV3_BLK16S_SILU_K2 : L.variant; break;
+      case CONV3S2_BLK16S_SILU: L.variant = kseg == 2 ? CONV3S2_BLK16S_SILU_K2 : L.variant; break;
+      case CONV3_R4_SILU: L.variant = kseg == 4 ? CONV3_R4_SILU_K4 : L.variant; break;
+      case CONV3S2_R4_SILU: L.variant = kseg == 2 ? CONV3S2_R4_SILU_K2 : L.variant; break;
+      case CONV1_BLK16S_SILU: L.variant = kseg == 2 ? CONV1_BLK16S_SILU_K2 : L.variant; break;
+      case CONV1_R4_SILU: L.variant = kseg == 2 ? CONV1_R4_SILU_K2 : L.variant; break;
+      case CONV1_R4_LINEAR: L.variant = kseg == 2 ? CONV1_R4_LINEAR_K2 : L.variant; break;
+      default: break;
+    }
+    if (conv_variant_kseg(L.variant) != kseg)
+      return fail(e, DANI_ERR_UNSUPPORTED, "layer %s (%d -> %d, %dx%d at level %d): no kernel for its %d-segment contraction", name.c_str(), cin, cout, k, k, scale, kseg);
   }
   L.Cin = cin; L.Cout = cout; L.ksize = k;
   L.CC = conv_variant_cc(L.variant);

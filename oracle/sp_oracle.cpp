@@ -637,7 +637,17 @@ ORC_API int orc_sp_extract(const uint8_t* img, int W, int H, int stride, const f
 // General convolution for the YOLOv5s restatement (oracle/yolo_oracle.py): any k, stride, padding, canonical
 // chain order (cp, ky, kx, cc) from acc = bias, activation 0 none / 1 ReLU / 2 SiLU.
 // SiLU canonical form: x / (1 + dani_expf(-x)).
+// Long contractions are a two-level sum: the input channels are cut into `kseg` equal contiguous
+// ranges -- 3x3 stride 1: 4 ranges from 256 channels, 2 from 128; 3x3 stride 2: 2 from 128; 1x1: 2 from 512; otherwise
+// 1 -- each range is one chain in
+// the order above (the bias opens range 0, the others start from 0), and the range sums are added left to right.
 // ============================================================================
+static int orc_kseg(int cin, int k, int stride) {
+  if (k == 3 && stride == 1) return cin >= 256 ? 4 : (cin >= 128 ? 2 : 1);
+  if (k == 3) return cin >= 128 ? 2 : 1;
+  if (k == 1) return cin >= 512 ? 2 : 1;
+  return 1;
+}
 ORC_API int orc_conv2d_ex(const float* in, int Cin, int H, int W, const float* w, const float* b, int Cout, int k,
                           int stride, int pad, int act, float* out) {
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
@@ -647,12 +657,14 @@ ORC_API int orc_conv2d_ex(const float* in, int Cin, int H, int W, const float* w
     for (int y = 0; y < H; y++)
       memcpy(&xp[((size_t)c * Hp + y + pad) * Wp + pad], &in[((size_t)c * H + y) * W], sizeof(float) * W);
   const int ncp = (Cin + 1) / 2;
+  const int kseg = (ncp % orc_kseg(Cin, k, stride) == 0) ? orc_kseg(Cin, k, stride) : 1, seg_cp = ncp / kseg;
 #pragma omp parallel for schedule(dynamic, 1)
   for (int co = 0; co < Cout; co++) {
-    std::vector<float> acc(Wo);
+    std::vector<float> acc(Wo), tot(Wo);
     for (int y = 0; y < Ho; y++) {
-      for (int x = 0; x < Wo; x++) acc[x] = b ? b[co] : 0.0f;
-      for (int cp = 0; cp < ncp; cp++)
+      for (int sg = 0; sg < kseg; sg++) {
+      for (int x = 0; x < Wo; x++) acc[x] = (sg == 0 && b) ? b[co] : 0.0f;
+      for (int cp = sg * seg_cp; cp < (sg + 1) * seg_cp; cp++)
         for (int ky = 0; ky < k; ky++)
           for (int kx = 0; kx < k; kx++)
             for (int cc = 0; cc < 2; cc++) {
@@ -667,9 +679,11 @@ ORC_API int orc_conv2d_ex(const float* in, int Cin, int H, int W, const float* w
                 for (int x = 0; x < Wo; x++) acc[x] = __builtin_fmaf(src[x * stride], wv, acc[x]);
               }
             }
+      for (int x = 0; x < Wo; x++) tot[x] = sg ? tot[x] + acc[x] : acc[x];
+      }
       float* dst = &out[((size_t)co * Ho + y) * Wo];
       for (int x = 0; x < Wo; x++) {
-        float v = acc[x];
+        float v = tot[x];
         if (act == 1) v = v > 0.0f ? v : 0.0f;
         else if (act == 2) v = v / (1.0f + dani_expf(-v));
         dst[x] = v;
