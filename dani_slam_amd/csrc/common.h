@@ -52,6 +52,9 @@ enum ConvVariant {
   // tiles (-> one 32-pixel row per workgroup), 2 segments for the long 1x1 layers
   CONV3_BLK16S_SILU_K2 = 23, CONV3S2_BLK16S_SILU_K2 = 24, CONV3_R4_SILU_K4 = 25, CONV3S2_R4_SILU_K2 = 26,
   CONV1_BLK16S_SILU_K2 = 27, CONV1_R4_SILU_K2 = 28, CONV1_R4_LINEAR_K2 = 29,
+  // SuperPoint's 1/2- and 1/4-resolution layers at small batch: 32-cout twins of the 8x32 tiles (plain and pooled) and
+  // 4x32-pixel tiles -- 2x / 4x the workgroups where one or two frames would leave most CUs with one workgroup or none
+  CONV3_ROW32N_RELU = 30, CONV3_ROW32N_RELU_POOL = 31, CONV3_R4_RELU = 32,
 };
 
 // Canonical K segmentation of a YOLOv5s convolution (conv_mfma.hip, Cfg::SEG; oracle/sp_oracle.cpp orc_conv2d_ex follows the

@@ -340,6 +340,10 @@ using CfgS2R4SiluK2      = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1, 2>;
 using CfgConv1Blk16sSiluK2 = Cfg<1, 1, 2, 16, 1, 32, ACT_SILU, false, 1, 2>;
 using CfgConv1R4SiluK2   = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 2>;
 using CfgConv1R4K2       = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1, 2>;
+// SuperPoint at small batch: narrow (32-cout) twins of the 8x32 tiles and 4x32-pixel tiles
+using CfgRow32nRelu      = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, false, 1>;
+using CfgRow32nReluPool  = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true, 1>;
+using CfgR4Relu          = Cfg<3, 1, 1, 32, 1, 8, ACT_RELU, false, 1>;
 
 template <class C>
 static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds) {
@@ -399,6 +403,9 @@ bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV1_BLK16S_SILU_K2: return launch_cfg<CfgConv1Blk16sSiluK2>(L, io, B, s, reserve_lds);
     case CONV1_R4_SILU_K2: return launch_cfg<CfgConv1R4SiluK2>(L, io, B, s, reserve_lds);
     case CONV1_R4_LINEAR_K2: return launch_cfg<CfgConv1R4K2>(L, io, B, s, reserve_lds);
+    case CONV3_ROW32N_RELU: return launch_cfg<CfgRow32nRelu>(L, io, B, s, reserve_lds);
+    case CONV3_ROW32N_RELU_POOL: return launch_cfg<CfgRow32nReluPool>(L, io, B, s, reserve_lds);
+    case CONV3_R4_RELU: return launch_cfg<CfgR4Relu>(L, io, B, s, reserve_lds);
   }
   return false;
 }

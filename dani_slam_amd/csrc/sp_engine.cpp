@@ -173,6 +173,14 @@ int dani_finalize_weights(dani_engine* e) {
       const int tiles = ((e->cfg.max_height / 8 + 15) / 16) * ((e->cfg.max_width / 8 + 15) / 16);
       if (e->cfg.max_batch * tiles * ((d.cout + 63) / 64) < 768) L.variant = conv_small_variant(L.variant);
     }
+    if (i >= 2 && i <= 5) {   // conv2a .. conv3b at small batch: more, smaller workgroups (same k order: bit-identical)
+      const int lvl = i <= 3 ? 2 : 4;                                   // resolution divisor of the layer's output (before pooling)
+      const int tiles = ((e->cfg.max_height / lvl + 7) / 8) * ((e->cfg.max_width / lvl + 31) / 32);
+      const int wgs = e->cfg.max_batch * tiles * ((d.cout + 63) / 64);
+      static const int small_wgs = getenv("DANI_SP_SMALL_WGS") ? atoi(getenv("DANI_SP_SMALL_WGS")) : 512;
+      const bool pooled = L.variant == CONV3_ROW32_RELU_POOL;
+      if (wgs < small_wgs) L.variant = pooled ? CONV3_ROW32N_RELU_POOL : (2 * wgs < small_wgs ? CONV3_R4_RELU : CONV3_ROW32N_RELU);
+    }
     L.Cin = d.cin; L.Cout = d.cout; L.ksize = d.k; L.CinPad = d.cin;
     L.CC = conv_variant_cc(L.variant);
     const int nco = conv_variant_nco(L.variant);

@@ -113,6 +113,15 @@ int yolo_pack_raw(dani_engine* e, YoloWeights* W, const std::string& name, const
     else if (k == 3) L.variant = CONV3_R4_SILU;
     else if (k == 1) L.variant = act ? CONV1_R4_SILU : CONV1_R4_LINEAR;
   }
+  if (scale <= 1 && k != 6) {   // 190x320 / 95x160 at small batch: 4x32-pixel x 32-cout tiles, 4x the workgroups (same k order)
+    const int tiles = ((kYH[scale] + 7) / 8) * ((kYW[scale] + 31) / 32);
+    static const int small_wgs = getenv("DANI_YOLO_SMALL_WGS") ? atoi(getenv("DANI_YOLO_SMALL_WGS")) : 256;
+    if (e->cfg.max_batch * tiles * ((cout + 63) / 64) < small_wgs) {
+      if (k == 3 && s == 2) L.variant = CONV3S2_R4_SILU;
+      else if (k == 3) L.variant = CONV3_R4_SILU;
+      else if (k == 1) L.variant = act ? CONV1_R4_SILU : CONV1_R4_LINEAR;
+    }
+  }
   // Long contractions: the canonical order is a sum of K segments (conv_kseg: a function of the layer's shape, the oracle
   // follows the same rule), each segment on its own wave(s) of a workgroup.  Such layers always take a small-tile variant.
   const int kseg = conv_kseg(cin, k, s);

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 sys.path.insert(0, ".")
 from dani_slam_amd import frontend, synth
-B = 8
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 eng = frontend.Engine(max_batch=B, weights=synth.superpoint_weights(0))
 frames = np.stack([synth.frame(i) for i in range(B)])
 dev = torch.from_numpy(frames).cuda()
