@@ -388,8 +388,12 @@ def main():
                          "note": f"dani_lg_set_gemm({key[8:].upper()}): {what} as six bf16 MFMAs over three-term operand splits, "
                                  "f32 accumulation; opt-in, not the headline"}
         eng.lg_set_gemm(eng.LG_GEMM_F32)
-        # BASELINE configs #2 and #3: one call at a time, as a live tracker issues them (src/Frame.cc:420-427, :813-860)
+        # BASELINE configs #2 and #3: one call at a time, as a live tracker issues them (src/Frame.cc:420-427, :813-860), on an
+        # engine built for that use (max_batch = 2: the engines pick their tile shapes for the batch they are built for)
         lat = {}
+        eng_big = eng
+        eng = frontend.Engine(device=local_rank, max_batch=2, max_width=W, max_height=H, weights=weights)
+        eng.yolo_set_classes(synth.COCO_NAMES, synth.DYNAMIC_NAMES)
         for key, mode, nb, what in (("config2_superpoint_extract_1_frame", 2, 1, "SPextractor::operator() on one 640x480 frame, 1024 keypoints"),
                                     ("config3_stereo_pair_sp_x2_plus_lightglue", 3, 2, "two extractions + one LightGlue pair (Frame::ComputeStereoMatches)")):
             eng.frontend_reset()
@@ -399,6 +403,8 @@ def main():
             lat[key] = {"median": pct(sm, 50), "p10": pct(sm, 10), "p90": pct(sm, 90), "calls": len(sm), "frames_per_call": nb,
                         "frames_per_s": round(nb * len(sm) / (sum(sm) * 1e-3), 2), "what": what}
         side["latency_b1_ms"] = lat
+        eng.close()
+        eng = eng_big
         eng.frontend_reset()
     gc.enable()
 
