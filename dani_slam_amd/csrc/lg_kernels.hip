@@ -317,8 +317,53 @@ __global__ __launch_bounds__(1024) void ln_gelu_kernel(float* hbuf, const float*
   }
 }
 
+// Small token counts (one or two pairs: 33-66 of the 64-token workgroups above on 256 CUs): 16 tokens per workgroup.  Lane =
+// (token l & 15, feature quarter l >> 4), wave g holds features [32g + 8q, 32g + 8q + 8) of its 16 tokens in 8 VGPRs; the
+// statistics are reduced over the 4 quarters by two shuffles and over the 16 waves through LDS.  Same arithmetic per element;
+// the order of the two reductions differs from ln_gelu_kernel's (LightGlue is held to 1e-3).
+__global__ __launch_bounds__(1024) void ln_gelu16_kernel(float* hbuf, const float* gamma, const float* beta, int T, int ld) {
+  __shared__ float red[16][16];
+  const int l = threadIdx.x & 63, tl = l & 15, q = l >> 4, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tok = blockIdx.x * 16 + tl;
+  const bool ok = tok < T;
+  float v[8];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    v[i] = ok ? (hbuf + (size_t)(g * 32 + q * 8 + i) * ld)[tok] : 0.0f;
+    s += v[i];
+  }
+  s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+  if (q == 0) red[g][tl] = s;
+  __syncthreads();
+  float tot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) tot += red[k][tl];
+  const float mean = tot * (1.0f / 512.0f);
+  __syncthreads();
+  float s2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { const float d = v[i] - mean; s2 += d * d; }
+  s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+  if (q == 0) red[g][tl] = s2;
+  __syncthreads();
+  float tv = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; k++) tv += red[k][tl];
+  const float rstd = 1.0f / sqrtf(tv * (1.0f / 512.0f) + 1e-5f);
+  if (!ok) return;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int f = g * 32 + q * 8 + i;
+    const float y = (v[i] - mean) * rstd * gamma[f] + beta[f];
+    (hbuf + (size_t)f * ld)[tok] = 0.5f * y * (1.0f + lg_erff(y * 0.70710678118654752440f));
+  }
+}
+
 void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(ln_gelu_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
+  static const int small_t = getenv("DANI_LN_SMALL_T") ? atoi(getenv("DANI_LN_SMALL_T")) : 64 * 128;   // fewer than 128 of the 64-token workgroups
+  if (T < small_t) hipLaunchKernelGGL(ln_gelu16_kernel, dim3((T + 15) / 16), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
+  else hipLaunchKernelGGL(ln_gelu_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -231,10 +231,11 @@ def test_match_groups_many_small_ragged_sets(lg_weights, sp_weights):
         assert all(abs(got[c] - want[c]) < 1e-3 for c in set(got) & set(want)), g
         assert all(0 <= i < len(a) and 0 <= j < len(b) for i, j in got), g                  # indices are local to the group
     assert total > 500 and wrong <= max(2, total // 100), (total, wrong)                    # near-tie flips only
-    # the groups agree with single calls through the plain entry point (same kernels, other batch geometry)
+    # the groups agree with single calls through the plain entry point (other batch geometry; a single small pair takes the
+    # 16-token LayerNorm kernel and the four-way key split: other reduction orders, scores within 1e-4)
     for g in (0, 7, 100):
         m, s = e.lg_match(k0[groups0[g]], d0[groups0[g]], k1[groups1[g]], d1[groups1[g]], SIZE, SIZE, 0.05)
-        assert np.array_equal(m, res[g][0]) and np.allclose(s, res[g][1], rtol=0, atol=1e-5)
+        assert np.array_equal(m, res[g][0]) and np.allclose(s, res[g][1], rtol=0, atol=1e-4)
     # SearchByBoW's shape: ONE group holding everything that was gathered (src/LGmatcher.cpp:257-314)
     rows0 = np.nonzero(node0 < 60)[0]; rows1 = np.nonzero(node1 < 60)[0]
     one = e.lg_match_groups(k0, d0, k1, d1, [rows0], [rows1], SIZE, SIZE, 0.05)[0]
