@@ -374,6 +374,8 @@ __global__ void posenc_kernel(const LgSet* sets, int nsets, const float* wr, flo
   const int set = blockIdx.y;
   const LgSet st = sets[set];
   const int i = blockIdx.x * 64 + threadIdx.x;   // position in the set's span: padded main region, then tail tokens
+  const int f0 = threadIdx.y * 8;                // 4 feature groups of 8 per token: 64 library sin / cos calls in one thread made
+                                                 // this the longest of LightGlue's small kernels (29 us for one pair)
   const int mp = (st.nmain + 31) & ~31, nt = st.n - st.nmain;
   int tok, kpi = -1;
   if (i < mp) { tok = st.tok_off + i; if (i < st.nmain) kpi = i; }
@@ -384,7 +386,7 @@ __global__ void posenc_kernel(const LgSet* sets, int nsets, const float* wr, flo
   float x = 0.0f, y = 0.0f;
   if (kpi >= 0) { x = (st.kp[2 * kpi] - sx) / scale; y = (st.kp[2 * kpi + 1] - sy) / scale; }
 #pragma unroll 4
-  for (int f = 0; f < 32; f++) {
+  for (int f = f0; f < f0 + 8; f++) {
     const float p = wr[2 * f] * x + wr[2 * f + 1] * y;
     cosb[(size_t)f * ld + tok] = cosf(p);
     sinb[(size_t)f * ld + tok] = sinf(p);
@@ -392,7 +394,7 @@ __global__ void posenc_kernel(const LgSet* sets, int nsets, const float* wr, flo
 }
 
 void launch_posenc(const LgSet* sets, int nsets, int max_span, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(posenc_kernel, dim3((max_span + 63) / 64, nsets), dim3(64), 0, s, sets, nsets, wr, cosb, sinb, ld);
+  hipLaunchKernelGGL(posenc_kernel, dim3((max_span + 63) / 64, nsets), dim3(64, 4), 0, s, sets, nsets, wr, cosb, sinb, ld);
 }
 
 // each set's token-major [n][256] descriptors (LgSet::desc) -> feature-major [256][ld] (zero for padding tokens)
