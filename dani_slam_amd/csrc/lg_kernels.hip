@@ -1515,24 +1515,27 @@ __global__ __launch_bounds__(64) void row_lse_kernel(const float* sim, int sim_l
   if (threadIdx.x == 0) lse_row[s0.dense_off + i] = mx + __logf(sm);
 }
 
-// column statistics + column argmax of (2*sim - lse_row[i] + ls0[i]): thread per column, CS_SPLIT-way row split per
+// column statistics + column argmax of (2*sim - lse_row[i] + ls0[i]): thread per column, SPLIT-way row split per
 // block (64 columns x 16 row groups = 1024 threads: the 4-way version left 136 workgroups of 4 waves for the chip)
-constexpr int CS_SPLIT = 16;
-__global__ __launch_bounds__(64 * CS_SPLIT) void col_stats_kernel(const float* sim, int sim_ld, size_t pstride, const LgSet* sets,
+// COLS x SPLIT = 1024 threads: 64 columns x 16 row groups for batches (the 4-way version left 136 workgroups of 4 waves for
+// the chip), 16 columns x 64 row groups for one or two pairs (17 workgroups of the first form walk 64 rows each in a serial
+// online-logsumexp chain: 26 us; 65 workgroups walking 16 rows each: the launch is four times shorter).
+template <int COLS, int SPLIT>
+__global__ __launch_bounds__(COLS * SPLIT) void col_stats_kernel(const float* sim, int sim_ld, size_t pstride, const LgSet* sets,
                                                         const float* lse_row, const float* logsig, float* lse_col,
                                                         int* m1, int ld) {
-  __shared__ float rmx[CS_SPLIT][64], rsm[CS_SPLIT][64], rbv[CS_SPLIT][64];
-  __shared__ int rbi[CS_SPLIT][64];
+  __shared__ float rmx[SPLIT][COLS], rsm[SPLIT][COLS], rbv[SPLIT][COLS];
+  __shared__ int rbi[SPLIT][COLS];
   const int pair = blockIdx.y;
   const LgSet s0 = sets[2 * pair], s1 = sets[2 * pair + 1];
-  const int lj = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int jj = blockIdx.x * 64 + lj;
+  const int lj = threadIdx.x % COLS, q = threadIdx.x / COLS;
+  const int jj = blockIdx.x * COLS + lj;
   const bool ok = jj < s1.n;
   const float* sp = sim + (size_t)pair * pstride + (ok ? jj : 0);
   // pass 1: max over rows (online logsumexp) and best score
   float mx = -1e30f, sm = 0.0f, bv = -3e38f;
   int bi = 0;
-  for (int i = q; i < s0.n; i += CS_SPLIT) {
+  for (int i = q; i < s0.n; i += SPLIT) {
     const float v = sp[(size_t)i * sim_ld];
     const float nm = fmaxf(mx, v);
     sm = sm * __expf(mx - nm) + __expf(v - nm);
@@ -1544,12 +1547,12 @@ __global__ __launch_bounds__(64 * CS_SPLIT) void col_stats_kernel(const float* s
   __syncthreads();
   if (q == 0 && ok) {
     float M = rmx[0][lj];
-    for (int k = 1; k < CS_SPLIT; k++) M = fmaxf(M, rmx[k][lj]);
+    for (int k = 1; k < SPLIT; k++) M = fmaxf(M, rmx[k][lj]);
     float S = 0.0f;
-    for (int k = 0; k < CS_SPLIT; k++) S += rsm[k][lj] * __expf(rmx[k][lj] - M);
+    for (int k = 0; k < SPLIT; k++) S += rsm[k][lj] * __expf(rmx[k][lj] - M);
     lse_col[s1.dense_off + jj] = M + __logf(S);
     float B = rbv[0][lj]; int I = rbi[0][lj];
-    for (int k = 1; k < CS_SPLIT; k++)
+    for (int k = 1; k < SPLIT; k++)
       if (rbv[k][lj] > B || (rbv[k][lj] == B && rbi[k][lj] < I)) { B = rbv[k][lj]; I = rbi[k][lj]; }
     m1[s1.dense_off + jj] = I;
   }
@@ -1584,8 +1587,12 @@ void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const
                              const float* logsig, float* lse_row, float* lse_col, int* m0, float* max0, int* m1, int ld,
                              hipStream_t s) {
   hipLaunchKernelGGL(row_lse_kernel, dim3(max_n, npairs), dim3(64), 0, s, sim, sim_ld, pstride, sets, lse_row, ld);
-  hipLaunchKernelGGL(col_stats_kernel, dim3((max_n + 63) / 64, npairs), dim3(64 * CS_SPLIT), 0, s, sim, sim_ld, pstride, sets, lse_row,
-                     logsig, lse_col, m1, ld);
+  if (((max_n + 63) / 64) * npairs < 64)
+    hipLaunchKernelGGL((col_stats_kernel<16, 64>), dim3((max_n + 15) / 16, npairs), dim3(1024), 0, s, sim, sim_ld, pstride, sets, lse_row,
+                       logsig, lse_col, m1, ld);
+  else
+    hipLaunchKernelGGL((col_stats_kernel<64, 16>), dim3((max_n + 63) / 64, npairs), dim3(1024), 0, s, sim, sim_ld, pstride, sets, lse_row,
+                       logsig, lse_col, m1, ld);
   hipLaunchKernelGGL(row_argmax_kernel, dim3(max_n, npairs), dim3(64), 0, s, sim, sim_ld, pstride, sets, lse_row, lse_col,
                      logsig, m0, max0);
 }
