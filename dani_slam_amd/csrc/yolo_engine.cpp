@@ -34,6 +34,10 @@ struct YoloContext {
   float* cand = nullptr; int* cand_count = nullptr;
   float* h_cand = nullptr; int* h_count = nullptr;
   std::vector<void*> dev_allocs, host_allocs;
+  // the Detect heads of the 48x80 and 24x40 levels run on a side stream as soon as their inputs exist (model.17 / model.20),
+  // under the rest of the chain, instead of at its end
+  hipStream_t side = nullptr;
+  hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
 };
 
 void yolo_release(dani_engine* e) {
@@ -43,6 +47,8 @@ void yolo_release(dani_engine* e) {
     if (!Y) continue;
     for (void* p : Y->dev_allocs) (void)hipFree(p);
     for (void* p : Y->host_allocs) (void)hipHostFree(p);
+    if (Y->side) (void)hipStreamDestroy(Y->side);
+    for (int i = 0; i < 2; i++) { if (Y->ev_in[i]) (void)hipEventDestroy(Y->ev_in[i]); if (Y->ev_out[i]) (void)hipEventDestroy(Y->ev_out[i]); }
     delete Y;
     c->yolo = nullptr;
   }
@@ -313,14 +319,31 @@ void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thres
   yolo_c3(W, Y, kC3[4], V("cat12"), V("b13"), B, s);
   yolo_conv(W, "model.14.conv", V("b13"), S("cat19", 128, 128), nullptr, B, s);  // x14 -> second half of cat19
   up("cat19", 128, 128, "cat16");
+  static const bool side_heads = !getenv("DANI_YOLO_NO_SIDE_HEADS");
+  if (side_heads && !Y->side) {
+    if (create_priority_stream(&Y->side) != hipSuccess) Y->side = nullptr;
+    for (int i = 0; i < 2 && Y->side; i++) { (void)hipEventCreateWithFlags(&Y->ev_in[i], hipEventDisableTiming); (void)hipEventCreateWithFlags(&Y->ev_out[i], hipEventDisableTiming); }
+  }
+  auto head_aside = [&](int i, const char* name, const char* in, const char* out) {   // head i: on the side stream once `in` is complete
+    if (!side_heads || !Y->side) return false;
+    (void)hipEventRecord(Y->ev_in[i], s);
+    (void)hipStreamWaitEvent(Y->side, Y->ev_in[i], 0);
+    yolo_conv(W, name, V(in), V(out), nullptr, B, Y->side);
+    (void)hipEventRecord(Y->ev_out[i], Y->side);
+    return true;
+  };
   yolo_c3(W, Y, kC3[5], V("cat16"), V("b17"), B, s);
+  const bool h0 = head_aside(0, "model.24.m.0", "b17", "raw0");
   yolo_conv(W, "model.18.conv", V("b17"), S("cat19", 0, 128), nullptr, B, s);
   yolo_c3(W, Y, kC3[6], V("cat19"), V("b20"), B, s);
+  const bool h1 = head_aside(1, "model.24.m.1", "b20", "raw1");
   yolo_conv(W, "model.21.conv", V("b20"), S("cat22", 0, 256), nullptr, B, s);
   yolo_c3(W, Y, kC3[7], V("cat22"), V("b23"), B, s);
-  yolo_conv(W, "model.24.m.0", V("b17"), V("raw0"), nullptr, B, s);
-  yolo_conv(W, "model.24.m.1", V("b20"), V("raw1"), nullptr, B, s);
+  if (!h0) yolo_conv(W, "model.24.m.0", V("b17"), V("raw0"), nullptr, B, s);
+  if (!h1) yolo_conv(W, "model.24.m.1", V("b20"), V("raw1"), nullptr, B, s);
   yolo_conv(W, "model.24.m.2", V("b23"), V("raw2"), nullptr, B, s);
+  if (h0) (void)hipStreamWaitEvent(s, Y->ev_out[0], 0);
+  if (h1) (void)hipStreamWaitEvent(s, Y->ev_out[1], 0);
   const ActDesc* raws[3] = {&b.at("raw0"), &b.at("raw1"), &b.at("raw2")};
   launch_yolo_decode(raws, score_thresh, Y->cand, Y->cand_count, YOLO_CAND_CAP, B, s);
 }
