@@ -233,6 +233,7 @@ struct SpCall {
   int wait_layer = 1;
   int reserve_lds_bytes = 0;          // fused call with YOLO on the second stream: unused dynamic LDS added to the conv layers in
   unsigned reserve_lds_mask = 0;      // reserve_lds_mask (bit i = layer i), so that a CU keeps a free slot for YOLO's workgroups
+  bool side_free = false;             // fused call without YOLO: the context's second stream is idle during the network (phase 0: always)
   bool host_cull = false;             // single-level calls: candidate NMS + read-back are enqueued in phase 1, without the
                                       // boxes; the dynamic-box cull (exact and idempotent at scale 1) runs on the host in phase 2
 };

@@ -138,6 +138,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   SpCall sp_call;
   sp_call.ctx = c; sp_call.keep_desc_on_device = true; sp_call.phase = 1;
   sp_call.host_cull = p->use_yolo && p->sp.nlevels == 1;
+  sp_call.side_free = !p->use_yolo;
   if (p->use_yolo) {   // tuning knobs of the slot reservation (defaults below are the measured optimum)
     static const int pad_kb = getenv("DANI_SP_LDS_PAD_KB") ? atoi(getenv("DANI_SP_LDS_PAD_KB")) : 0;
     static const unsigned pad_mask = getenv("DANI_SP_LDS_PAD_MASK") ? (unsigned)strtoul(getenv("DANI_SP_LDS_PAD_MASK"), nullptr, 0) : 0u;

@@ -282,18 +282,37 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       launch_conv1a(limg, B, L.H, L.W, lstride, lframe, e->w1a, e->b1a, L.act[0], s);
       if (lprof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
       const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
+      // One or two frames: the detector head (convPa, convPb, softmax) and the descriptor head (convDa, convDb, norm) are
+      // independent branches behind conv4b and each launches fewer workgroups than the chip has slots for; when the context's
+      // second stream is idle (no YOLO beside this call) the descriptor branch runs there, next to the detector branch.
+      static const bool fork_off = getenv("DANI_SP_NO_HEAD_FORK") != nullptr;
+      const bool fork = !fork_off && B <= 2 && !lprof && (phase == 0 || call.side_free) && !call.wait_event;
       for (int i = 1; i < 12; i++) {
         if (call.wait_event && l == 0 && i == call.wait_layer) HIP_TRY(e, hipStreamWaitEvent(s, call.wait_event, 0));
         const int reserve = (call.reserve_lds_mask >> i) & 1 ? call.reserve_lds_bytes : 0;
-        if (!launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, s, reserve)) {
+        hipStream_t si = (fork && i >= 10) ? c->stream2 : s;
+        if (fork && i == 8) {   // conv4b is enqueued: the descriptor branch may start behind it
+          HIP_TRY(e, hipEventRecord(c->ev_y0, s));
+          HIP_TRY(e, hipStreamWaitEvent(c->stream2, c->ev_y0, 0));
+        }
+        if (!launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, si, reserve)) {
           (void)hipStreamSynchronize(s);
+          if (fork) (void)hipStreamSynchronize(c->stream2);
           return fail(e, DANI_ERR_UNSUPPORTED, "%s at %dx%d: activation tensor exceeds the conv kernel's 32-bit addressing range", kSp[i].name, L.W, L.H);
         }
         if (lprof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
       }
+      if (fork) {
+        launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, c->stream2);
+        HIP_TRY(e, hipEventRecord(c->ev_y1, c->stream2));
+        launch_softmax_d2s(L.act[9], L.prob, B, s);
+        HIP_TRY(e, hipStreamWaitEvent(s, c->ev_y1, 0));   // everything later on the main stream sees both branches
+        if (l == NL - 1) HIP_TRY(e, hipEventRecord(c->ev[1], s));
+      } else {
       if (l == NL - 1) HIP_TRY(e, hipEventRecord(c->ev[1], s));
       launch_softmax_d2s(L.act[9], L.prob, B, s);
       launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, s);
+      }
     }
     HIP_TRY(e, hipGetLastError());
     if (phase == 1) {   // network enqueued; the caller continues with phase 2 once the boxes are known
