@@ -56,6 +56,28 @@ hipError_t create_priority_stream(hipStream_t* s) {
   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
 }
 
+// Streams and events of a context, every creation checked: a context either has all of them or is torn down again.
+hipError_t context_create_sync(Context* c) {
+  hipError_t rc = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (rc == hipSuccess) rc = create_priority_stream(&c->stream2);
+  for (hipEvent_t* ev : {&c->ev_desc, &c->ev_y0, &c->ev_y1, &c->ev_lg0, &c->ev_lg1})
+    if (rc == hipSuccess) rc = hipEventCreate(ev);
+  for (hipEvent_t* ev : {&c->ev_fork0, &c->ev_fork1})   // ordering only (SuperPoint head fork), never timed
+    if (rc == hipSuccess) rc = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  for (auto& ev : c->ev) if (rc == hipSuccess) rc = hipEventCreate(&ev);
+  for (auto& ev : c->lev) if (rc == hipSuccess) rc = hipEventCreate(&ev);
+  if (rc != hipSuccess) context_destroy_sync(c);
+  return rc;
+}
+void context_destroy_sync(Context* c) {
+  for (auto& ev : c->ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+  for (auto& ev : c->lev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+  for (hipEvent_t* ev : {&c->ev_desc, &c->ev_y0, &c->ev_y1, &c->ev_lg0, &c->ev_lg1, &c->ev_fork0, &c->ev_fork1})
+    if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
+  if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
+  if (c->stream2) { (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
+}
+
 // A free context of the pool; when all n_contexts are in use the caller WAITS for one (calls are short and always
 // release): more concurrent callers than contexts is a throughput matter, never an error.
 Context* acquire(dani_engine* e) {
@@ -131,12 +153,7 @@ int dani_engine_create(const dani_config* cfg, dani_engine** out) {
   if (hipSetDevice(e->device) != hipSuccess) { delete e; return fail(nullptr, DANI_ERR_HIP, "hipSetDevice failed"); }
   for (int i = 0; i < e->cfg.n_contexts; i++) {
     Context* c = new Context();
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        create_priority_stream(&c->stream2) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "hipStreamCreate failed"); }
-    (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
-    (void)hipEventCreate(&c->ev_lg0); (void)hipEventCreate(&c->ev_lg1);
-    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
-    for (auto& ev : c->lev) (void)hipEventCreate(&ev);
+    if (context_create_sync(c) != hipSuccess) { delete c; dani_engine_destroy(e); return fail(nullptr, DANI_ERR_HIP, "stream / event creation failed"); }
     e->ctxs.push_back(c);
   }
   *out = e;
@@ -153,12 +170,8 @@ void dani_engine_destroy(dani_engine* e) {
   lg_release(e); yolo_release(e); seq_release(e);
   for (Context* c : e->ctxs) {
     free_buffers(c);
-    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
-    for (auto& ev : c->lev) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {c->ev_desc, c->ev_y0, c->ev_y1, c->ev_lg0, c->ev_lg1}) if (ev) (void)hipEventDestroy(ev);
     if (c->scan_ws) (void)hipFree(c->scan_ws);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    context_destroy_sync(c);
     delete c;
   }
   for (void* p : e->weight_allocs) (void)hipFree(p);

@@ -33,6 +33,7 @@ struct Context {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // YOLO (concurrent with the SuperPoint conv stack) and overlapped D2H copies
   hipEvent_t ev_desc = nullptr, ev_y0 = nullptr, ev_y1 = nullptr, ev_lg0 = nullptr, ev_lg1 = nullptr;
+  hipEvent_t ev_fork0 = nullptr, ev_fork1 = nullptr;   // fork / join of SuperPoint's two heads (ordering only, timing disabled)
   int W = 0, H = 0, B = 0;  // shapes the buffers are built for
   int nlevels = 0;
   float scale_factor = 0.0f;
@@ -248,9 +249,12 @@ struct YoloCall {
 struct LgCall {
   Context* ctx = nullptr;
   std::function<void()>* overlap = nullptr;   // host work of the caller to run while the forward pass executes
+  int32_t out_stride = 0;   // matches / scores of pair p start at p * out_stride (0: p * cap); `cap` stays the per-pair write limit
 };
 
 hipError_t create_priority_stream(hipStream_t* s);
+hipError_t context_create_sync(Context* c);   // both streams + every event, all checked (nothing left behind on failure)
+void context_destroy_sync(Context* c);
 Context* acquire(dani_engine* e);
 void release(dani_engine* e, Context* c);
 

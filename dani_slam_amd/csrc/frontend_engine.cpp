@@ -51,7 +51,9 @@ thread_local SeqState* t_last_seq = nullptr;
 
 void seq_release(dani_engine* e) {
   std::lock_guard<std::mutex> lk(e->mu);
-  for (auto& kv : e->seqs) { if (t_last_seq == kv.second) t_last_seq = nullptr; delete kv.second; }
+  // dani_engine_destroy has synchronised every stream: a descriptor read-back still pending here (defer_desc) is CANCELLED,
+  // never copied -- the caller's array may be gone by now (include/dani_frontend.h, dani_frontend_finish_pending)
+  for (auto& kv : e->seqs) { if (t_last_seq == kv.second) t_last_seq = nullptr; kv.second->pend_desc = nullptr; delete kv.second; }
   e->seqs.clear();
 }
 
@@ -76,6 +78,14 @@ int dani_frontend_reset(dani_engine* e, int32_t sequence) {
   std::lock_guard<std::mutex> lk(S->mu);
   finish_pending_desc(S);
   if (S->ctx) S->ctx->prev_n = 0;
+  return DANI_OK;
+}
+
+int dani_frontend_finish_pending(dani_engine* e, int32_t sequence) {
+  if (!e) return DANI_ERR_INVALID;
+  SeqState* S = seq_state(e, sequence);
+  std::lock_guard<std::mutex> lk(S->mu);
+  if (S->pend_desc) { HIP_TRY(e, hipSetDevice(e->device)); finish_pending_desc(S); }
   return DANI_OK;
 }
 
@@ -115,12 +125,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   HIP_TRY(e, hipSetDevice(e->device));
   if (!S->ctx) {
     Context* c = new Context();
-    HIP_TRY(e, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(e, create_priority_stream(&c->stream2));
-    (void)hipEventCreate(&c->ev_desc); (void)hipEventCreate(&c->ev_y0); (void)hipEventCreate(&c->ev_y1);
-    (void)hipEventCreate(&c->ev_lg0); (void)hipEventCreate(&c->ev_lg1);
-    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
-    for (auto& ev : c->lev) (void)hipEventCreate(&ev);
+    if (context_create_sync(c) != hipSuccess) { delete c; return fail(e, DANI_ERR_HIP, "stream / event creation failed for sequence %d", sequence); }
     c->busy = true;   // never handed out by acquire()
     { std::lock_guard<std::mutex> lk(e->mu); e->ctxs.push_back(c); }
     S->ctx = c;
@@ -260,14 +265,12 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     const float sz[2] = {(float)W, (float)H};
     LgCall lg_call;
     lg_call.ctx = c; lg_call.overlap = &move_desc;
+    lg_call.out_stride = 2 * match_cap;   // a pair writes into the right frame's slot only: at most match_cap entries
     rc = lg_match_impl(e, lg_call, P, 2 * c->kcap, 1, c->d_kimg, c->d_descout, n0.data(), c->d_kimg + (size_t)c->kcap * 2,
                        c->d_descout + (size_t)c->kcap * 256, n1.data(), sz, sz, p->lg_threshold, matches + (size_t)match_cap * 2,
-                       scores + match_cap, 2 * match_cap, kk.data());
+                       scores + match_cap, match_cap, kk.data());
+    for (int k = 0; k < P; k++) { k_out[2 * k] = 0; k_out[2 * k + 1] = kk[k]; }   // also on DANI_ERR_CAPACITY: the sizes needed
     if (rc) { move_desc(); (void)hipStreamSynchronize(c->stream); return rc; }
-    for (int k = 0; k < P; k++) {
-      k_out[2 * k] = 0; k_out[2 * k + 1] = kk[k];
-      if (kk[k] > match_cap) { move_desc(); (void)hipStreamSynchronize(c->stream); return fail(e, DANI_ERR_CAPACITY, "pair %d: %d matches (> %d)", k, kk[k], match_cap); }
-    }
   }
   const bool synced = cache_enqueued;   // LightGlue ran: its final synchronise covered the cache copies
   const bool defer = p->defer_desc && !p->match_previous && desc;   // split form: dani_frontend_match_resident finishes the read-back

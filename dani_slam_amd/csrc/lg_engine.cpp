@@ -443,8 +443,9 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
   for (int p = 0; p < P; p++) {
     const LgSet& a = L->last_sets[2 * p]; const LgSet& b = L->last_sets[2 * p + 1];
     int k = 0;
-    int32_t* mo = matches + (size_t)p * cap * 2;
-    float* so = scores + (size_t)p * cap;
+    const size_t ostride = call.out_stride > 0 ? (size_t)call.out_stride : (size_t)cap;
+    int32_t* mo = matches + (size_t)p * ostride * 2;
+    float* so = scores + (size_t)p * ostride;
     if (a.n > 0 && b.n > 0)
       for (int i = 0; i < a.n; i++) {
         const int jj = L->h_m0[a.dense_off + i];

@@ -910,6 +910,12 @@ __global__ __launch_bounds__(64 * NKQ) void attn_k4_kernel(const float* Q, const
     soff[u] = d * ld + 4 * q4;
     loff[u] = d * AT_STRIDE + 4 * q4;
   }
+#define ATK4_WAVE_SYNC()                                                               \
+  {                                                                                    \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                             \
+    __builtin_amdgcn_wave_barrier();                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                             \
+  }
 #define ATK4_PREFETCH(kt_)                                                             \
   {                                                                                    \
     _Pragma("unroll") for (int u = 0; u < 8; u++) {                                    \
@@ -924,6 +930,7 @@ __global__ __launch_bounds__(64 * NKQ) void attn_k4_kernel(const float* Q, const
 #pragma unroll
       for (int c = 0; c < 4; c++) { sK[loff[u] + c] = pk[u][c]; sV[loff[u] + c] = pv[u][c]; }
     }
+    ATK4_WAVE_SYNC();   // the tile is written by this wave's lanes and read across them: order the ds ops (no instruction emitted)
     if (kt + 1 < kt1) ATK4_PREFETCH(kt + 1);
     f32x16 s;
 #pragma unroll
@@ -952,8 +959,10 @@ __global__ __launch_bounds__(64 * NKQ) void attn_k4_kernel(const float* Q, const
     l += ls;
     m = m_new;
     attn_pv_tile(sV, s, o, j, h);
+    ATK4_WAVE_SYNC();   // reads of this tile before the next tile's (or the merge state's) stores
   }
 #undef ATK4_PREFETCH
+#undef ATK4_WAVE_SYNC
   if (ntail > 0 && kq == NKQ - 1) attn_tail_keys(sTK, ntail, qreg, o, m, l, h);   // the last quarter is the shortest
   // ---- merge: quarters 1..3 leave their state in their OWN tile region (64 lanes x 34 floats), quarter 0 folds them in
   if (kq != 0) {

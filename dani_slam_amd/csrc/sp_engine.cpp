@@ -292,8 +292,8 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
         const int reserve = (call.reserve_lds_mask >> i) & 1 ? call.reserve_lds_bytes : 0;
         hipStream_t si = (fork && i >= 10) ? c->stream2 : s;
         if (fork && i == 8) {   // conv4b is enqueued: the descriptor branch may start behind it
-          HIP_TRY(e, hipEventRecord(c->ev_y0, s));
-          HIP_TRY(e, hipStreamWaitEvent(c->stream2, c->ev_y0, 0));
+          HIP_TRY(e, hipEventRecord(c->ev_fork0, s));
+          HIP_TRY(e, hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
         }
         if (!launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, si, reserve)) {
           (void)hipStreamSynchronize(s);
@@ -302,16 +302,15 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
         }
         if (lprof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
       }
+      if (l == NL - 1) HIP_TRY(e, hipEventRecord(c->ev[1], s));   // end of the main stream's convolutions, on both paths
       if (fork) {
         launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, c->stream2);
-        HIP_TRY(e, hipEventRecord(c->ev_y1, c->stream2));
+        HIP_TRY(e, hipEventRecord(c->ev_fork1, c->stream2));
         launch_softmax_d2s(L.act[9], L.prob, B, s);
-        HIP_TRY(e, hipStreamWaitEvent(s, c->ev_y1, 0));   // everything later on the main stream sees both branches
-        if (l == NL - 1) HIP_TRY(e, hipEventRecord(c->ev[1], s));
+        HIP_TRY(e, hipStreamWaitEvent(s, c->ev_fork1, 0));   // everything later on the main stream sees both branches
       } else {
-      if (l == NL - 1) HIP_TRY(e, hipEventRecord(c->ev[1], s));
-      launch_softmax_d2s(L.act[9], L.prob, B, s);
-      launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, s);
+        launch_softmax_d2s(L.act[9], L.prob, B, s);
+        launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, s);
       }
     }
     HIP_TRY(e, hipGetLastError());

@@ -38,6 +38,7 @@ struct YoloContext {
   // under the rest of the chain, instead of at its end
   hipStream_t side = nullptr;
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+  bool side_tried = false;   // creation of the side stream is attempted once per context
 };
 
 void yolo_release(dani_engine* e) {
@@ -210,6 +211,24 @@ int yolo_ensure(dani_engine* e, Context* c, YoloContext** out, int B, size_t img
     Y = c->yolo;
   }
   *out = Y;
+  // side stream of the two early Detect heads: it and its four events exist completely or not at all (then the heads
+  // simply stay on the chain's stream)
+  static const bool side_heads = !getenv("DANI_YOLO_NO_SIDE_HEADS");
+  if (side_heads && !Y->side && !Y->side_tried) {
+    Y->side_tried = true;
+    bool ok = create_priority_stream(&Y->side) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++)
+      ok = hipEventCreateWithFlags(&Y->ev_in[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&Y->ev_out[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      for (int i = 0; i < 2; i++) {
+        if (Y->ev_in[i]) { (void)hipEventDestroy(Y->ev_in[i]); Y->ev_in[i] = nullptr; }
+        if (Y->ev_out[i]) { (void)hipEventDestroy(Y->ev_out[i]); Y->ev_out[i] = nullptr; }
+      }
+      if (Y->side) { (void)hipStreamDestroy(Y->side); Y->side = nullptr; }
+      (void)hipGetLastError();
+    }
+  }
   if (Y->B >= B && Y->d_img_bytes >= img_bytes) return 0;
   for (void* p : Y->dev_allocs) (void)hipFree(p);
   for (void* p : Y->host_allocs) (void)hipHostFree(p);
@@ -319,17 +338,14 @@ void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thres
   yolo_c3(W, Y, kC3[4], V("cat12"), V("b13"), B, s);
   yolo_conv(W, "model.14.conv", V("b13"), S("cat19", 128, 128), nullptr, B, s);  // x14 -> second half of cat19
   up("cat19", 128, 128, "cat16");
-  static const bool side_heads = !getenv("DANI_YOLO_NO_SIDE_HEADS");
-  if (side_heads && !Y->side) {
-    if (create_priority_stream(&Y->side) != hipSuccess) Y->side = nullptr;
-    for (int i = 0; i < 2 && Y->side; i++) { (void)hipEventCreateWithFlags(&Y->ev_in[i], hipEventDisableTiming); (void)hipEventCreateWithFlags(&Y->ev_out[i], hipEventDisableTiming); }
-  }
-  auto head_aside = [&](int i, const char* name, const char* in, const char* out) {   // head i: on the side stream once `in` is complete
-    if (!side_heads || !Y->side) return false;
-    (void)hipEventRecord(Y->ev_in[i], s);
-    (void)hipStreamWaitEvent(Y->side, Y->ev_in[i], 0);
+  // head i on the side stream once `in` is complete (stream and events come from yolo_ensure).  A failed record / wait
+  // before the launch leaves the head on the chain's stream; after the launch the chain waits for the side stream instead.
+  bool side_sync = false;
+  auto head_aside = [&](int i, const char* name, const char* in, const char* out) {
+    if (!Y->side) return false;
+    if (hipEventRecord(Y->ev_in[i], s) != hipSuccess || hipStreamWaitEvent(Y->side, Y->ev_in[i], 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     yolo_conv(W, name, V(in), V(out), nullptr, B, Y->side);
-    (void)hipEventRecord(Y->ev_out[i], Y->side);
+    if (hipEventRecord(Y->ev_out[i], Y->side) != hipSuccess) { (void)hipGetLastError(); side_sync = true; }
     return true;
   };
   yolo_c3(W, Y, kC3[5], V("cat16"), V("b17"), B, s);
@@ -342,8 +358,9 @@ void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thres
   if (!h0) yolo_conv(W, "model.24.m.0", V("b17"), V("raw0"), nullptr, B, s);
   if (!h1) yolo_conv(W, "model.24.m.1", V("b20"), V("raw1"), nullptr, B, s);
   yolo_conv(W, "model.24.m.2", V("b23"), V("raw2"), nullptr, B, s);
-  if (h0) (void)hipStreamWaitEvent(s, Y->ev_out[0], 0);
-  if (h1) (void)hipStreamWaitEvent(s, Y->ev_out[1], 0);
+  if (h0 && hipStreamWaitEvent(s, Y->ev_out[0], 0) != hipSuccess) side_sync = true;
+  if (h1 && hipStreamWaitEvent(s, Y->ev_out[1], 0) != hipSuccess) side_sync = true;
+  if (side_sync) { (void)hipGetLastError(); (void)hipStreamSynchronize(Y->side); }   // ordering by brute force, never a silent race
   const ActDesc* raws[3] = {&b.at("raw0"), &b.at("raw1"), &b.at("raw2")};
   launch_yolo_decode(raws, score_thresh, Y->cand, Y->cand_count, YOLO_CAND_CAP, B, s);
 }

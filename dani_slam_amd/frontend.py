@@ -117,6 +117,7 @@ def load_library():
                                         C.c_int32, C.c_int32, C.POINTER(_FrontendParams), _f, _f, _f, C.c_int32, _i32, _i32,
                                         _i32, C.c_int32, _i32, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_reset.argtypes = [C.c_void_p, C.c_int32]
+    lib.dani_frontend_finish_pending.argtypes = [C.c_void_p, C.c_int32]
     lib.dani_frontend_export_features.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, _i32]
     lib.dani_frontend_match_resident.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_timings.argtypes = [C.c_void_p, _f]
@@ -446,14 +447,19 @@ class Engine:
     def frontend_reset(self, sequence=0):
         self._check(self.lib.dani_frontend_reset(self.h, sequence))
 
+    def frontend_finish_pending(self, sequence=0):
+        """Complete a descriptor read-back left running by frontend_batch(defer_desc=True); keeps the cached predecessor."""
+        self._check(self.lib.dani_frontend_finish_pending(self.h, sequence))
+
     def frontend_batch(self, gray, bgr=None, nfeatures=1024, iniTh=0.015, minTh=0.007, use_yolo=True, match_previous=True,
                        lg_threshold=0.05, lapping=(0, 0), want_desc=True, device_ptrs=None, shape=None, box_cap=512, copy=True,
-                       sequence=0, scaleFactor=1.2, nlevels=1, stereo_pairs=False, defer_desc=False):
+                       sequence=0, scaleFactor=1.2, nlevels=1, stereo_pairs=False, defer_desc=False, match_cap=None):
         """gray [B,H,W] u8 and bgr [B,H,W,3] u8 host arrays, or device_ptrs=(gray_ptr, bgr_ptr) + shape=(B,H,W).
         Returns a list of per-frame dicts: kpts, resp, desc (or None), mono_index, boxes [k,4], matches [K,2], scores.
         copy=False returns views into buffers that the next call overwrites.
         stereo_pairs: frames (2k, 2k+1) are left / right images; frame 2k+1 carries the left-vs-right matches
-        (dani_frontend_params.pair_mode = 1, Frame::ComputeStereoMatches)."""
+        (dani_frontend_params.pair_mode = 1, Frame::ComputeStereoMatches).
+        match_cap: per-frame capacity of the match outputs (default: the keypoint capacity)."""
         if defer_desc and copy:
             raise ValueError("defer_desc needs copy=False: the descriptor rows are complete only after frontend_match_resident")
         if device_ptrs is None:
@@ -484,18 +490,26 @@ class Engine:
         if not hasattr(self, "_fe_bufs_by_seq"):
             self._fe_bufs_by_seq = {}
         bufs = self._fe_bufs_by_seq.get(sequence)
-        key = (B, cap, box_cap, want_desc)
+        mcap = int(match_cap) if match_cap else cap
+        key = (B, cap, box_cap, want_desc, mcap)
         if bufs is None or bufs[0] != key:
+            if bufs is not None:
+                # the engine may still hold a pointer into the old descriptor array (defer_desc): finish that read-back
+                # before the array is dropped
+                self._check(self.lib.dani_frontend_finish_pending(self.h, sequence))
+            guard = 64   # canary words behind the match arrays (tests check that a capacity error wrote nothing past them)
+            mflat = np.full(B * mcap * 2 + guard, -7777, np.int32); scflat = np.full(B * mcap + guard, -7777.0, np.float32)
             bufs = (key, dict(k=np.empty((B, cap, 2), np.float32), r=np.empty((B, cap), np.float32),
                               d=np.empty((B, cap, 256), np.float32) if want_desc else None,
                               n=np.zeros(B, np.int32), mono=np.zeros(B, np.int32),
                               boxes=np.zeros((B, box_cap, 4), np.int32), nb=np.zeros(B, np.int32),
-                              m=np.zeros((B, cap, 2), np.int32), sc=np.zeros((B, cap), np.float32), ko=np.zeros(B, np.int32)))
+                              m=mflat[:B * mcap * 2].reshape(B, mcap, 2), sc=scflat[:B * mcap].reshape(B, mcap),
+                              m_guard=mflat[B * mcap * 2:], sc_guard=scflat[B * mcap:], ko=np.zeros(B, np.int32)))
             self._fe_bufs_by_seq[sequence] = bufs
         o = bufs[1]
         rc = self.lib.dani_frontend_batch(self.h, sequence, gp, gs, bp, bs, on_dev, B, W, H, C.byref(p), _fp(o["k"]), _fp(o["r"]),
                                           _fp(o["d"]) if want_desc else None, cap, _ip(o["n"]), _ip(o["mono"]),
-                                          _ip(o["boxes"]), box_cap, _ip(o["nb"]), _ip(o["m"]), _fp(o["sc"]), cap, _ip(o["ko"]))
+                                          _ip(o["boxes"]), box_cap, _ip(o["nb"]), _ip(o["m"]), _fp(o["sc"]), mcap, _ip(o["ko"]))
         self._check(rc)
         res = []
         for b in range(B):

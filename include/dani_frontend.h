@@ -292,6 +292,10 @@ DANI_API int dani_frontend_match_resident(dani_engine* e, int32_t sequence, cons
                                           float lg_threshold, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out);
 /* Forget the cached previous frame (start of a new sequence). */
 DANI_API int dani_frontend_reset(dani_engine* e, int32_t sequence);
+/* Complete a descriptor read-back that a defer_desc call left running (no-op otherwise); the cached predecessor is kept.
+ * Call it before the `desc` array of that call is freed or reused while no dani_frontend_match_resident follows.
+ * dani_engine_destroy CANCELS a pending read-back instead (nothing is written into `desc` after it returns). */
+DANI_API int dani_frontend_finish_pending(dani_engine* e, int32_t sequence);
 /* Stage wall times (ms) of the last dani_frontend_batch on this thread: [0] yolo, [1] superpoint, [2] lightglue, [3] total. */
 DANI_API int dani_frontend_timings(dani_engine* e, float* ms4);
 

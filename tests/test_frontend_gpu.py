@@ -164,6 +164,24 @@ def test_stereo_pair_mode(sp_weights):
                 _assert_matches_like_oracle(w, refs[2 * k], refs[2 * k + 1], out[2 * k + 1], 20)
     with pytest.raises(frontend.DaniError):
         e.frontend_batch(gray[:3], None, nfeatures=NF, use_yolo=False, stereo_pairs=True)      # odd number of frames
+    # match capacity below a pair's match count: DANI_ERR_CAPACITY, every slot holds at most match_cap entries, nothing is
+    # written into the following frame's slot or past the end of the caller's [B][match_cap] arrays (canary words), and
+    # k_out reports the size that was needed
+    full = e.frontend_batch(gray[:4], None, nfeatures=NF, use_yolo=False, stereo_pairs=True)
+    need = [len(full[1]["matches"]), len(full[3]["matches"])]
+    mc = min(need) // 2
+    assert mc >= 8
+    with pytest.raises(frontend.DaniError):
+        e.frontend_batch(gray[:4], None, nfeatures=NF, use_yolo=False, stereo_pairs=True, match_cap=mc)
+    o = e._fe_bufs_by_seq[0][1]
+    assert o["m"].shape == (4, mc, 2)
+    assert np.all(o["m_guard"] == -7777) and np.all(o["sc_guard"] == -7777.0)
+    assert np.all(o["m"][0] == -7777) and np.all(o["m"][2] == -7777)           # left frames' slots: untouched
+    assert np.array_equal(o["m"][1], full[1]["matches"][:mc]) and np.array_equal(o["m"][3], full[3]["matches"][:mc])
+    assert np.array_equal(o["sc"][3], full[3]["scores"][:mc])
+    assert [int(o["ko"][1]), int(o["ko"][3])] == need and int(o["ko"][0]) == 0
+    ok = e.frontend_batch(gray[:4], None, nfeatures=NF, use_yolo=False, stereo_pairs=True, match_cap=max(need))   # exactly enough
+    assert np.array_equal(ok[3]["matches"], full[3]["matches"]) and np.array_equal(ok[1]["scores"], full[1]["scores"])
     e.close()
 
 
@@ -223,4 +241,14 @@ def test_split_form_equals_fused_call_and_takes_a_foreign_predecessor(sp_weights
     assert all(np.array_equal(a["desc"], b["desc"]) for a, b in zip(xd, fused[:4]))
     with pytest.raises(ValueError):
         e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False, defer_desc=True)   # copy=True would copy unfinished rows
-    e.close()
+    # a deferred read-back must never outlive its array: the binding completes it (dani_frontend_finish_pending) before it
+    # replaces the sequence's buffer set (another batch size here), and destroying the engine with one pending cancels it
+    xd = e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False, defer_desc=True, copy=False)
+    e.frontend_batch(gray[:2], bgr[:2], nfeatures=NF, match_previous=False)                      # new key -> old buffers dropped
+    assert all(np.array_equal(a["desc"], b["desc"]) for a, b in zip(xd, fused[:4]))              # ... after they were completed
+    xd = e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False, defer_desc=True, copy=False)
+    e.frontend_finish_pending()
+    assert all(np.array_equal(a["desc"], b["desc"]) for a, b in zip(xd, fused[:4]))
+    e.frontend_finish_pending()                                                                  # nothing pending: no-op
+    e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False, defer_desc=True, copy=False)
+    e.close()                                                                                    # pending read-back cancelled
