@@ -14,7 +14,7 @@ synthetic SuperPoint weights carry the centred descriptor head, so LightGlue fin
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
-  roofline      -- the dominant kernel by total time (linear_fm_kernel<64>, LightGlue's linear layers, 55 launches per
+  roofline      -- the dominant kernel by total time (linear_rs_kernel, LightGlue's linear layers, 55 launches per
                    step) priced against the gfx950 FP32 matrix peak, from HIP events recorded on the engine's own
                    stream around every launch during sampled timed steps; `other_kernels` prices the attention and
                    the pooled conv kernels the same way; `traffic` is the PMC figure committed under profiles/;
@@ -149,7 +149,7 @@ def main():
                     help="hand the frames over as HOST buffers (PCIe-inclusive rate for DESIGN.md; never the headline value)")
     ap.add_argument("--sequences", type=int, default=1,
                     help="independent image sequences (cameras) processed concurrently per GPU, one host thread each; "
-                         "steps are dealt round-robin to them.  2 gives a few % more frames/s by filling host-sync gaps, but the "
+                         "steps are dealt round-robin to them.  2 gives a few %% more frames/s by filling host-sync gaps, but the "
                          "per-kernel HIP-event durations behind `roofline` then include time shared with the other "
                          "sequence's kernels, so the default keeps one sequence for clean attribution")
     ap.add_argument("--lg-gemm", choices=("f32", "bf16x3", "bf16x3_all"), default="f32",
@@ -436,7 +436,7 @@ def main():
             # second kernel by total time: LightGlue attention (18 launches per step)
             attn_ms, attn_flop, attn_launches = float(attn[0]), float(attn[1]), int(round(attn[2]))
             attn_achieved = attn_flop / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
-            # dominant kernel of the full front-end by total time (profiles/: linear_fm_kernel<64>, 55 launches per step)
+            # dominant kernel of the full front-end by total time (profiles/: linear_rs_kernel, 55 launches per step)
             lin_ms, lin_flop, lin_launches = float(lin[0]), float(lin[1]), int(round(lin[2]))
             achieved = lin_flop / (lin_ms * 1e-3) / 1e12 if lin_ms > 0 else 0.0
             traffic, traffic_src = None, None
@@ -463,7 +463,7 @@ def main():
                                              + ("; posted after a step's extraction and waited for one extraction later: the LightGlue of "
                                                 "step t runs behind the extraction of step t + 1" if pipelined else "; lock-step") if boundary else
                                              f"frame-sharded x{world}, no data-path collective")}
-            res["roofline"] = {"bound": "mfma", "kernel": "linear_fm_kernel<64> (LightGlue feature-major linear layers: 6 per layer x 9 + final_proj)",
+            res["roofline"] = {"bound": "mfma", "kernel": "linear_rs_kernel<NCB,UQ> (LightGlue feature-major linear layers, register-streaming form of lin_rs.h: 6 per layer x 9 + final_proj; linear_fm_kernel<64> where its grid fills the chip better)",
                                "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "launches_per_step": lin_launches,

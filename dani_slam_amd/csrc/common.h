@@ -190,9 +190,11 @@ bool launch_linear_x3(const float* x0, int K0, const float* x1, int K1, const vo
                       int rot_rows, float alpha, hipStream_t s);
 size_t x3_packed_u16(int out, int in);
 void pack_linear_x3(const float* w_row_major, int out, int in, uint16_t* dst);
+// w_rs: the same weights in pack_linear_rs layout (linear_rs_kernel, lin_rs.h); nullptr = linear_fm_kernel only
 bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
-                      int rot_rows, float alpha, hipStream_t s);
+                      int rot_rows, float alpha, hipStream_t s, const float* w_rs = nullptr);
+void pack_linear_rs_host(const float* w_row_major, int out, int in, float* dst);   // [out][in] -> lin_rs.h layout (out * in floats)
 void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s);
 void launch_posenc(const LgSet* sets, int nsets, int max_span, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s);
 void launch_desc_to_fm(const LgSet* sets, int nsets, int max_span, float* x, int ld, hipStream_t s);

@@ -12,7 +12,7 @@ namespace eng {
 
 constexpr int LG_LAYERS = 9;
 
-struct LgLinear { float* w = nullptr; float* b = nullptr; void* w3 = nullptr; int out = 0, in = 0; };   // w3: bf16x3 split of w (lg_x3.hip)
+struct LgLinear { float* w = nullptr; float* b = nullptr; void* w3 = nullptr; float* wrs = nullptr; int out = 0, in = 0; };   // w3: bf16x3 split of w (lg_x3.hip); wrs: lin_rs.h layout
 struct LgBlockW { LgLinear a, b, c, ffn0, ffn3; float* ln_g = nullptr; float* ln_b = nullptr; };  // self: a=Wqkv,b=out_proj; cross: a=to_qk,b=to_v,c=to_out
 struct LgWeights {
   bool ready = false;
@@ -86,6 +86,11 @@ int lg_pack_raw(dani_engine* e, const std::vector<float>& w, const std::vector<f
   int rc;
   if ((rc = lg_upload(e, wp, &L->w))) return rc;
   if ((rc = lg_upload(e, bp, &L->b))) return rc;
+  if (out % 128 == 0 && in % 32 == 0) {   // the register-streaming form's operand layout (linear_rs_kernel)
+    std::vector<float> wr((size_t)out * in);
+    pack_linear_rs_host(w.data(), out, in, wr.data());
+    if ((rc = lg_upload(e, wr, &L->wrs))) return rc;
+  }
   // the same weight split into three bf16 terms, for the DANI_LG_GEMM_BF16X3 option
   std::vector<uint16_t> w3(x3_packed_u16(out, in));
   pack_linear_x3(w.data(), out, in, w3.data());
@@ -268,7 +273,7 @@ bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
   auto lin = [&](const LgLinear& l, const float* x0, int K0, const float* x1, int K1, float* y, const float* res, int rot, float alpha) {
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
     if (gemm != DANI_LG_GEMM_F32) ok = launch_linear_x3(x0, K0, x1, K1, l.w3, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s) && ok;
-    else ok = launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s) && ok;
+    else ok = launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s, l.wrs) && ok;
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
   };
   for (int i = 0; i < LG_LAYERS; i++) {

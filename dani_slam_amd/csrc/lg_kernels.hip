@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "lin_epilogue.h"
+#include "lin_rs.h"
 #include "x3_common.h"
 
 namespace dani {
@@ -231,10 +232,26 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
 
 int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = the 64-token tile)
 
+void pack_linear_rs_host(const float* w_row_major, int out, int in, float* dst) { pack_linear_rs(w_row_major, out, in, dst); }
+
+int g_lin_force_rs = -1;  // tuning hook: -1 = choose per shape (linear_rs_choose), 0 = never, 1..3 = linear_rs_kernel with that NCB
+
 bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
-                      int rot_rows, float alpha, hipStream_t s) {
+                      int rot_rows, float alpha, hipStream_t s, const float* w_rs) {
   if (OUT % 64 || rot_rows % 64 || (size_t)OUT * ld >= ((size_t)1 << 30)) return false;   // contract of lin_epilogue.h: refused, not launched
+  // register-streaming form (lin_rs.h) where the grid it gives fills the chip at least as well as the LDS-tiled one
+  static const int rs_env = getenv("DANI_LIN_RS") ? atoi(getenv("DANI_LIN_RS")) : -1;
+  const int rs_mode = g_lin_force_rs >= 0 ? g_lin_force_rs : rs_env;
+  if (w_rs && rs_mode != 0 && g_lin_force_tt == 0) {
+    const int ncb = rs_mode > 0 ? rs_mode : linear_rs_choose(OUT, K0 + K1, T, ld);
+    if (ncb > 0) {
+      LinRsArgs r;
+      r.x0 = x0; r.x1 = x1 ? x1 : x0; r.K0 = K0; r.K1 = K1; r.wq = w_rs; r.bias = bias_packed; r.y = y; r.res = res;
+      r.cosb = cosb; r.sinb = sinb; r.OUT = OUT; r.T = T; r.ld = ld; r.rot_rows = rot_rows; r.alpha = alpha; r.n_tail_wg = 0;
+      if (launch_linear_rs(ncb, r, s)) return true;
+    }
+  }
   LinArgs a;
   a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w_packed; a.bias = bias_packed; a.y = y; a.res = res;
   a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot_rows; a.alpha = alpha;

@@ -4,6 +4,7 @@
 //        (add -DDANI_CONV_STAMPS for the core clock of workgroup 0 and the entry / first-chunk / loop-done / exit timeline of every workgroup)
 #include "../../dani_slam_amd/csrc/lg_kernels.hip"
 #include "lin_ring_kernels.inc"
+#include "lin_rs_kernels.inc"
 #include <algorithm>
 #include <cstdio>
 #include <cmath>
@@ -12,10 +13,35 @@
 #include <vector>
 using namespace dani;
 // tt: 0 / 64 / 128 / 256 = the product launcher (with its tuning hook), >= 10000 = a ring variant (lin_ring_kernels.inc)
+static float* g_wq = nullptr;            // weights in linear_rsw_kernel's layout (re-packed per shape by prepare_wq)
+static std::vector<float> g_wt_host;    // the packed weights of the shipped kernel, on the host
+static bool prepare_wq(int OUT, int K) {
+  std::vector<float> wq((size_t)OUT * K);
+  repack_rsw(g_wt_host.data(), OUT, K, wq.data());
+  return hipMemcpy(g_wq, wq.data(), wq.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+}
 static bool launch_any(int tt, const float* x0, int K0, const float* x1, int K1, const float* w, const float* b, float* y, int OUT, int T,
                        int ld, const float* res, const float* cosb, const float* sinb, int rot, float alpha) {
+  if (tt >= 50000) {   // the product launcher with the register-streaming form: 50000 = its own choice, 5000N = NCB forced
+    g_lin_force_tt = 0; g_lin_force_rs = tt == 50000 ? -1 : tt - 50000;
+    const bool ok = launch_linear_fm(x0, K0, x1, K1, w, b, y, OUT, T, ld, res, cosb, sinb, rot, alpha, 0, g_wq);
+    g_lin_force_rs = 0;
+    return ok;
+  }
+  if (tt >= 40000) {
+    LinArgs a;
+    a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w; a.bias = b; a.y = y; a.res = res;
+    a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot; a.alpha = alpha; a.ksplit = 0;
+    return launch_linear_rsw(tt, a, g_wq, 0);
+  }
+  if (tt >= 30000) {
+    LinArgs a;
+    a.x0 = x0; a.x1 = x1 ? x1 : x0; a.K0 = K0; a.K1 = K1; a.w = w; a.bias = b; a.y = y; a.res = res;
+    a.cosb = cosb; a.sinb = sinb; a.OUT = OUT; a.T = T; a.ld = ld; a.rot_rows = rot; a.alpha = alpha; a.ksplit = 0;
+    return launch_linear_rs(tt, a, 0);
+  }
   if (tt >= 10000) return launch_linear_variant(tt, x0, K0, x1, K1, w, b, y, OUT, T, ld, res, cosb, sinb, rot, alpha, 0);
-  g_lin_force_tt = tt;
+  g_lin_force_tt = tt; g_lin_force_rs = 0;
   return launch_linear_fm(x0, K0, x1, K1, w, b, y, OUT, T, ld, res, cosb, sinb, rot, alpha, 0);
 }
 __global__ void fill_rand(float* p, size_t n, unsigned seed) {
@@ -27,8 +53,10 @@ __global__ void fill_rand(float* p, size_t n, unsigned seed) {
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 int main(int argc, char** argv) {
-  std::vector<int> Ts;
+  std::vector<int> Ts, variants;
   for (int i = 1; i < argc; i++) Ts.push_back(atoi(argv[i]));
+  if (const char* v = getenv("LIN_VARIANTS")) { for (const char* q = v; *q;) { variants.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; } }
+  if (variants.empty()) variants = {0};
   if (Ts.empty()) Ts = {16384, 16416, 16448, 16896};
   const int ld = 70000;
   float *X, *Y, *Wt, *Bs, *C;
@@ -41,13 +69,18 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(fill_rand, dim3(1), dim3(256), 0, 0, Bs, (size_t)768, 3u);
   hipLaunchKernelGGL(fill_rand, dim3(1024), dim3(256), 0, 0, C, (size_t)64 * ld, 4u);
   CK(hipDeviceSynchronize());
+  CK(hipMalloc(&g_wq, (size_t)768 * 512 * 4));
+  g_wt_host.resize((size_t)768 * 512);
+  CK(hipMemcpy(g_wt_host.data(), Wt, g_wt_host.size() * 4, hipMemcpyDeviceToHost));
   if (getenv("LIN_CHECK")) {   // ring variants against the shipped kernel, bit for bit, on every shape
     const int T = 16416;
     float* Y2; CK(hipMalloc(&Y2, (size_t)768 * ld * 4));
     std::vector<float> r0((size_t)768 * T), r1((size_t)768 * T);
     struct S2 { int out, k0, k1, rot; bool res; } sh2[] = {{768, 256, 0, 512, false}, {512, 256, 256, 0, false}, {256, 512, 0, 0, true}};
     for (const S2& sh : sh2)
-      for (int tt : {10323, 20164, 20163, 20322}) {
+      for (int tt : variants) {
+        if (tt == 0) continue;
+        prepare_wq(sh.out, sh.k0 + sh.k1);
         launch_any(0, X, sh.k0, sh.k1 ? X + (size_t)512 * ld : nullptr, sh.k1, Wt, Bs, Y, sh.out, T, ld, sh.res ? X + (size_t)600 * ld : nullptr, C, C + (size_t)32 * ld, sh.rot, 0.7f);
         launch_any(tt, X, sh.k0, sh.k1 ? X + (size_t)512 * ld : nullptr, sh.k1, Wt, Bs, Y2, sh.out, T, ld, sh.res ? X + (size_t)600 * ld : nullptr, C, C + (size_t)32 * ld, sh.rot, 0.7f);
         CK(hipDeviceSynchronize());
@@ -67,9 +100,10 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 300; i++) launch_linear_fm(X, 256, X + (size_t)256 * ld, 256, Wt, Bs, Y, 512, 16384, ld, nullptr, C, C + (size_t)32 * ld, 0, 1.0f, 0);
   CK(hipDeviceSynchronize());
   for (const Shape& sh : shapes)
-    for (int T : Ts)
-    for (int tt : {0}) {
+    for (int T : Ts) if (prepare_wq(sh.out, sh.k0 + sh.k1))
+    for (int tt : variants) {
       std::vector<double> us;
+      if (!launch_any(tt, X, sh.k0, sh.k1 ? X + (size_t)512 * ld : nullptr, sh.k1, Wt, Bs, Y, sh.out, T, ld, sh.res ? Y : nullptr, C, C + (size_t)32 * ld, sh.rot, 1.0f)) continue;
       for (int rd = 0; rd < 7; rd++) {
         CK(hipEventRecord(a, 0));
         for (int i = 0; i < 10; i++)
