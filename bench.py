@@ -470,7 +470,7 @@ def main():
                                "avg_launch_ms": round(lin_ms / max(lin_launches, 1), 4),
                                "algorithmic_gflop_per_step": round(lin_flop / 1e9, 2),
                                "other_kernels": {
-                                   "attn_kernel<4> (LightGlue f32 flash attention, 9 self + 9 cross launches; attn_ks_kernel below 512 workgroups)": {
+                                   "attn_rs_kernel (LightGlue f32 flash attention, register-streaming form of attn_rs.h, 9 self + 9 cross launches; attn_ks_kernel / attn_k4_kernel below 512 workgroups)": {
                                        "achieved": round(attn_achieved, 3), "frac": round(attn_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
                                        "avg_launch_ms": round(attn_ms / max(attn_launches, 1), 4), "launches_per_step": attn_launches,
                                        "algorithmic_gflop_per_step": round(attn_flop / 1e9, 2)},

@@ -248,7 +248,7 @@ bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
     if (ncb > 0) {
       LinRsArgs r;
       r.x0 = x0; r.x1 = x1 ? x1 : x0; r.K0 = K0; r.K1 = K1; r.wq = w_rs; r.bias = bias_packed; r.y = y; r.res = res;
-      r.cosb = cosb; r.sinb = sinb; r.OUT = OUT; r.T = T; r.ld = ld; r.rot_rows = rot_rows; r.alpha = alpha; r.n_tail_wg = 0;
+      r.cosb = cosb; r.sinb = sinb; r.OUT = OUT; r.T = T; r.ld = ld; r.rot_rows = rot_rows; r.alpha = alpha; r.n_tail_wg = 0; r.tail_tok0 = 0;
       if (launch_linear_rs(ncb, r, s)) return true;
     }
   }
@@ -600,16 +600,25 @@ __device__ __forceinline__ void attn_tail_query(const float* Q, const float* K, 
       for (int d = 0; d < 64; d++) o[d] = fmaf(pr, col[d], o[d] * alpha);
       m = m_new;
     }
-    // wave-level reduction: lane d ends up with O[d] of this wave's keys
+    // wave-level reduction: lane d ends up with O[d] of this wave's keys.  Reduce-scatter butterfly: at width w a lane keeps
+    // the half of its vector that its bit w selects and receives the partner's copy of that half -- 63 exchanges instead of
+    // the 64 x 6 of one full wave sum per d (these workgroups share their SIMDs with MFMA-bound main waves: every vector
+    // instruction here is an issue slot taken from them).
     const float M = wave_max(m);
     const float w = __builtin_amdgcn_exp2f(m - M);
     const float Lw = wave_sumf(l * w);
-    float out = 0.0f;
 #pragma unroll
-    for (int d = 0; d < 64; d++) {
-      const float tot = wave_sumf(o[d] * w);
-      if (lane == d) out = tot;
+    for (int d = 0; d < 64; d++) o[d] *= w;
+#pragma unroll
+    for (int wd = 32; wd >= 1; wd >>= 1) {
+      const bool up = (lane & wd) != 0;
+#pragma unroll
+      for (int i = 0; i < wd; i++) {
+        const float keep = up ? o[i + wd] : o[i], send = up ? o[i] : o[i + wd];
+        o[i] = keep + __shfl_xor(send, wd);
+      }
     }
+    const float out = o[0];
     xch[wave * 66 + lane] = out;
     if (lane == 0) { xch[wave * 66 + 64] = M; xch[wave * 66 + 65] = Lw; }
     __syncthreads();
@@ -1402,7 +1411,11 @@ __global__ __launch_bounds__(256, 2) void attn_x3w_kernel(const float* Q, const 
   }
 }
 
-int g_attn_force = 0;   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel, 4 = attn_x3w_kernel, 5 = attn_k4_kernel
+}  // namespace dani
+#include "attn_rs.h"
+namespace dani {
+
+int g_attn_force = 0;   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel, 4 = attn_x3w_kernel, 5 = attn_k4_kernel, 6 = attn_rs_kernel
 
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_mp, int max_tail, int cross, float scale, hipStream_t s, int x3) {
@@ -1414,8 +1427,18 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
   // 128-query workgroups (no key split, half the tile staging per MFMA, no merge) once they fill the chip's 512 resident
   // slots in whole rounds; below that the key-split kernel's twice as many, half as long workgroups balance better.
   // At 16 x 1025 keypoints (512 workgroups = one round): 150.1 vs 156.0 us (tools/probes/attn_bench.hip).
-  else if (g_attn_force != 1 && (g_attn_force == 2 || ((max_mp + 127) / 128) * 4 * nsets >= 512))
+  else if (g_attn_force != 1 && (g_attn_force == 2 || g_attn_force == 6 || g_attn_force == 7 || ((max_mp + 127) / 128) * 4 * nsets >= 512)) {
+    // register-streaming form (attn_rs.h) unless DANI_ATTN_RS=0 or the probe asks for the LDS-tiled kernel (force 2)
+    static const bool rs_off = getenv("DANI_ATTN_RS") && atoi(getenv("DANI_ATTN_RS")) == 0;
+    if (g_attn_force == 6 || (g_attn_force == 0 && !rs_off))
+      // ring of 8 loads, 2 waves per SIMD: equal to the ring of 4 at 3 waves per SIMD without tail queries, 2-3 us faster with
+      // them (tools/probes/attn_bench.hip, profiles/r03_attn_rs_probe.txt; force 7 = the ring of 4)
+      hipLaunchKernelGGL(attn_rs_kernel<8>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+    else if (g_attn_force == 7)
+      hipLaunchKernelGGL(attn_rs_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+    else
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+  }
   // fewer key-split workgroups than CUs (one pair of 1024 keypoints: 136): four key quarters per 32-query block instead
   else if (g_attn_force == 5 || (g_attn_force == 0 && ((max_mp + 63) / 64) * 4 * nsets <= 256)) {
     static bool attr_set_dev[64] = {};   // per device; idempotent: a race between two first callers sets the same values twice

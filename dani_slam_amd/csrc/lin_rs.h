@@ -39,7 +39,8 @@ struct LinRsArgs {
   float* y; const float* res; const float* cosb; const float* sinb;
   int OUT, T, ld, rot_rows;
   float alpha;
-  int n_tail_wg;                            // workgroups [0, n_tail_wg) serve the last T % 128 tokens (multiple of 8)
+  int n_tail_wg;                            // workgroups [0, n_tail_wg) serve the tokens from tail_tok0 on in 32 x 32 blocks (multiple of 8)
+  int tail_tok0;                            // (T / 128) * 128, or 0: every token goes through the tail role (small launches)
 };
 
 // [out][in] row-major -> [out block of 32][k-quad][lane = h * 32 + row][4 k-pairs]
@@ -61,7 +62,7 @@ __device__ __forceinline__ void linear_rs_tail(const LinRsArgs& a, int unit, flo
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int oblocks = a.OUT / 32;
   const int tb = unit / oblocks, ob = unit % oblocks;
-  const int tok = (a.T / 128) * 128 + tb * 32 + j;
+  const int tok = a.tail_tok0 + tb * 32 + j;
   const int K = a.K0 + a.K1, nq = K / 8, nqw = nq / 4;   // K is a multiple of 32
   rs_f32x16 acc;
 #pragma unroll
@@ -106,14 +107,14 @@ template <int NCB, int UQ>
 __global__ __launch_bounds__(256, NCB == 1 ? 3 : (NCB == 2 ? 2 : 1)) void linear_rs_kernel(LinRsArgs a) {
   __shared__ float tail_lds[3 * 64 * 17];
   if ((int)blockIdx.x < a.n_tail_wg) {
-    const int units = ((a.T % 128 + 31) / 32) * (a.OUT / 32);
+    const int units = ((a.T - a.tail_tok0 + 31) / 32) * (a.OUT / 32);
     if ((int)blockIdx.x < units) linear_rs_tail(a, blockIdx.x, tail_lds);
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int GO = 4 * NCB * 32;                  // outputs per workgroup
-  const int otiles = a.OUT / GO, ntiles = a.T / 128;   // full token tiles only
+  const int otiles = a.OUT / GO, ntiles = a.tail_tok0 / 128;   // full token tiles only
   // 1-D grid, XCD-aware as linear_fm_kernel: all out groups of a token tile on one XCD, back to back (n_tail_wg % 8 == 0)
   const int id = blockIdx.x - a.n_tail_wg;
   const int xcd = id & 7, slot = id >> 3;
@@ -264,13 +265,16 @@ inline int linear_rs_choose(int OUT, int K, int T, int ld) {
   return best_cost <= cost_fm ? best : 0;
 }
 
-inline bool launch_linear_rs(int ncb, const LinRsArgs& a0, hipStream_t s) {
+inline bool launch_linear_rs(int ncb, const LinRsArgs& a0, hipStream_t s) {   // ncb: 1..3, or 4 = all-tail form
   LinRsArgs a = a0;
   const int K = a.K0 + a.K1;
-  if (a.OUT % (128 * ncb) || K % 32 || a.K0 % 8 || a.ld % 4 || a.rot_rows % 32 || (size_t)a.OUT * a.ld >= ((size_t)1 << 30)) return false;
-  const int units = ((a.T % 128 + 31) / 32) * (a.OUT / 32);
+  if (a.OUT % (128 * (ncb == 4 ? 1 : ncb)) || K % 32 || a.K0 % 8 || a.ld % 4 || a.rot_rows % 32 || (size_t)a.OUT * a.ld >= ((size_t)1 << 30)) return false;
+  const bool all_tail = ncb == 4;   // code 4: no 128-token tiles at all, every token in 32 x 32 K-split blocks
+  if (all_tail) ncb = 1;
+  a.tail_tok0 = all_tail ? 0 : (a.T / 128) * 128;
+  const int units = ((a.T - a.tail_tok0 + 31) / 32) * (a.OUT / 32);
   a.n_tail_wg = (units + 7) / 8 * 8;
-  const unsigned g = (unsigned)(a.n_tail_wg + ((a.T / 128 + 7) / 8 * 8) * (a.OUT / (128 * ncb)));
+  const unsigned g = (unsigned)(a.n_tail_wg + ((a.tail_tok0 / 128 + 7) / 8 * 8) * (a.OUT / (128 * ncb)));
   if (g == 0) return true;
   if (ncb == 1) hipLaunchKernelGGL((linear_rs_kernel<1, 4>), dim3(g), dim3(256), 0, s, a);
   else if (ncb == 2) hipLaunchKernelGGL((linear_rs_kernel<2, 4>), dim3(g), dim3(256), 0, s, a);
