@@ -57,36 +57,36 @@ typedef float rs_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int rs_acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---- tail role: one 32-output x 32-token block per workgroup, K split over the four waves ------------------------------
+// NQW = k-quads per wave (K / 32): ALL of a wave's operand loads are issued up front (straight-line code: hipcc counts the
+// waits itself), so a block costs one memory round trip plus its K / 8 MFMAs -- these workgroups exist for latency
+// (the tail tokens of a large launch, every token of a small one), not for throughput.
+template <int NQW>
 __device__ __forceinline__ void linear_rs_tail(const LinRsArgs& a, int unit, float* lds) {
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int oblocks = a.OUT / 32;
   const int tb = unit / oblocks, ob = unit % oblocks;
   const int tok = a.tail_tok0 + tb * 32 + j;
-  const int K = a.K0 + a.K1, nq = K / 8, nqw = nq / 4;   // K is a multiple of 32
+  constexpr int nq = NQW * 4;
+  const float* wb = a.wq + ((size_t)ob * nq + wave * NQW) * 256 + lane * 4;
+  const unsigned boff = (unsigned)h * (unsigned)a.ld + (unsigned)min(tok, a.T - 1);
+  const float* xs1 = a.x1 - (size_t)a.K0 * a.ld;
+  rs_f32x4 av[NQW]; float bv[NQW][4];
+#pragma unroll
+  for (int u = 0; u < NQW; u++) {
+    const int q = wave * NQW + u;
+    av[u] = *reinterpret_cast<const rs_f32x4*>(wb + (size_t)u * 256);
+    const float* rb = ((8 * q < a.K0) ? a.x0 : xs1) + (size_t)(8 * q) * a.ld;
+#pragma unroll
+    for (int i = 0; i < 4; i++) bv[u][i] = rb[(size_t)(2 * i) * a.ld + boff];
+  }
   rs_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = wave ? 0.0f : a.bias[ob * 32 + rs_acc_row(r, h)];
-  const float* wb = a.wq + (size_t)ob * nq * 256 + lane * 4;
-  const unsigned boff = (unsigned)h * (unsigned)a.ld + (unsigned)min(tok, a.T - 1);
-  const float* xs1 = a.x1 - (size_t)a.K0 * a.ld;
-  for (int qq = 0; qq < nqw; qq += 4) {   // this wave's quads wave * nqw + qq .. + 3: loads first, then 16 MFMAs
-    rs_f32x4 av[4]; float bv[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int q = min(wave * nqw + qq + u, nq - 1);
-      av[u] = *reinterpret_cast<const rs_f32x4*>(wb + (size_t)q * 256);
-      const float* rb = ((8 * q < a.K0) ? a.x0 : xs1) + (size_t)(8 * q) * a.ld;
+  for (int u = 0; u < NQW; u++)
 #pragma unroll
-      for (int i = 0; i < 4; i++) bv[u][i] = rb[(size_t)(2 * i) * a.ld + boff];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (qq + u < nqw) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][i], acc, 0, 0, 0);
-      }
-  }
+    for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][i], acc, 0, 0, 0);
   float* xch = lds + ((wave - 1) * 64 + lane) * 17;
   if (wave) {
 #pragma unroll
@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : (NCB == 2 ? 2 : 1)) void linear
   __shared__ float tail_lds[3 * 64 * 17];
   if ((int)blockIdx.x < a.n_tail_wg) {
     const int units = ((a.T - a.tail_tok0 + 31) / 32) * (a.OUT / 32);
-    if ((int)blockIdx.x < units) linear_rs_tail(a, blockIdx.x, tail_lds);
+    if ((int)blockIdx.x < units) {
+      if (a.K0 + a.K1 == 256) linear_rs_tail<8>(a, blockIdx.x, tail_lds);
+      else linear_rs_tail<16>(a, blockIdx.x, tail_lds);   // K = 512 (launch_linear_rs admits 256 and 512 only)
+    }
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -268,7 +271,7 @@ inline int linear_rs_choose(int OUT, int K, int T, int ld) {
 inline bool launch_linear_rs(int ncb, const LinRsArgs& a0, hipStream_t s) {   // ncb: 1..3, or 4 = all-tail form
   LinRsArgs a = a0;
   const int K = a.K0 + a.K1;
-  if (a.OUT % (128 * (ncb == 4 ? 1 : ncb)) || K % 32 || a.K0 % 8 || a.ld % 4 || a.rot_rows % 32 || (size_t)a.OUT * a.ld >= ((size_t)1 << 30)) return false;
+  if (a.OUT % (128 * (ncb == 4 ? 1 : ncb)) || (K != 256 && K != 512) || a.K0 % 8 || a.ld % 4 || a.rot_rows % 32 || (size_t)a.OUT * a.ld >= ((size_t)1 << 30)) return false;
   const bool all_tail = ncb == 4;   // code 4: no 128-token tiles at all, every token in 32 x 32 K-split blocks
   if (all_tail) ncb = 1;
   a.tail_tok0 = all_tail ? 0 : (a.T / 128) * 128;

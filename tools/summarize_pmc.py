@@ -53,11 +53,17 @@ for k, d in agg.items():
     out[k] = e
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
-for k, e in out.items():
-    if dom in k:
-        json.dump({"kernel": k, "hbm_bytes_per_launch": round(e.get("hbm_bytes_per_launch", 0)),
-                   "source": f"profiles/{tag}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, KiB->B, avg over the kernel's launches)",
-                   "mfma_busy_frac": e.get("mfma_busy_frac")},
-                  open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-        print("dominant:", k, json.dumps({x: e[x] for x in e if x in ("mfma_busy_frac", "hbm_bytes_per_launch", "avg_duration_ns_profiled")}))
+# the dominant kernel may have several template instantiations (linear_rs_kernel<NCB, UQ>): launch-weighted average
+match = [(k, e) for k, e in out.items() if dom in k]
+if match:
+    n = sum(e["launches_sampled"] for _, e in match)
+    hbm = sum(e.get("hbm_bytes_per_launch", 0) * e["launches_sampled"] for _, e in match) / n
+    busy = [e["mfma_busy_frac"] * e["launches_sampled"] for _, e in match if "mfma_busy_frac" in e]
+    json.dump({"kernel": " | ".join(k for k, _ in match), "hbm_bytes_per_launch": round(hbm),
+               "source": f"profiles/{tag}_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, KiB->B, launch-weighted average over the instantiations listed)",
+               "mfma_busy_frac": (sum(busy) / n) if busy else None,
+               "per_instantiation": {k: {"launches_sampled": e["launches_sampled"], "hbm_bytes_per_launch": round(e.get("hbm_bytes_per_launch", 0)),
+                                         "mfma_busy_frac": e.get("mfma_busy_frac"), "avg_duration_ns_profiled": e.get("avg_duration_ns_profiled")} for k, e in match}},
+              open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    print("dominant:", [k for k, _ in match], "hbm bytes per launch", round(hbm))
 print("wrote profiles/%s_pmc_summary.json" % tag)
