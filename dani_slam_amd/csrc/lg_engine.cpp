@@ -7,6 +7,7 @@ using namespace dani::eng;
 // ================================================================================================
 // LightGlue
 // ================================================================================================
+namespace dani { extern int g_lin_force_rs, g_attn_force; }
 namespace dani {
 namespace eng {
 
@@ -313,6 +314,13 @@ LgContext* last_lg(dani_engine* e) {
 }  // namespace dani
 
 extern "C" {
+
+int dani_lg_set_kernel_option(const char* name, int32_t value) {
+  if (!name) return DANI_ERR_INVALID;
+  if (!strcmp(name, "lin_rs")) { if (value < -1 || value > 4) return DANI_ERR_INVALID; dani::g_lin_force_rs = value; return DANI_OK; }
+  if (!strcmp(name, "attn")) { if (value < 0 || value > 7) return DANI_ERR_INVALID; dani::g_attn_force = value; return DANI_OK; }
+  return DANI_ERR_INVALID;
+}
 
 int dani_lg_set_gemm(dani_engine* e, int32_t mode) {
   if (!e) return DANI_ERR_INVALID;

@@ -147,6 +147,12 @@ DANI_API int dani_last_timings(dani_engine* e, float* ms, int32_t n);
 #define DANI_LG_GEMM_BF16X3 1
 #define DANI_LG_GEMM_BF16X3_ALL 2
 DANI_API int dani_lg_set_gemm(dani_engine* e, int32_t mode);
+/* Kernel selection of the f32 LightGlue path, process-wide, for A/B tests and measurements (results agree within the
+ * tolerances of DESIGN.md; defaults = the shipped choice).  name:
+ *   "lin_rs"    -1 = per shape (default), 0 = LDS-tiled linear_fm_kernel only, 1..3 = linear_rs_kernel with that tile
+ *   "attn"       0 = per shape (default), 2 = LDS-tiled attn_kernel<4>, 6 / 7 = attn_rs_kernel with a ring of 8 / 4 loads
+ * Returns DANI_ERR_INVALID for an unknown name. */
+DANI_API int dani_lg_set_kernel_option(const char* name, int32_t value);
 
 /* Replaces LightGlue::matchDescriptors + normalizeKeypoints + filterMatches (src/LightGlue.cpp:18-122), as
  * called from Frame::ComputeStereoMatches (src/Frame.cc:860), LGmatcher::SearchByBoW (src/LGmatcher.cpp:314) and

@@ -244,3 +244,50 @@ def test_match_groups_many_small_ragged_sets(lg_weights, sp_weights):
     with pytest.raises(frontend.DaniError):
         e.lg_match_groups(k0, d0, k1, d1, [np.array([len(k0)])], [np.array([0])], SIZE, SIZE)   # row index out of range
     e.close()
+
+
+def test_register_streaming_kernels_match_the_lds_tiled_ones(lg_weights, sp_weights):
+    """Round 3's kernels against the ones they replace, in one process (dani_lg_set_kernel_option): the register-streaming
+    linear layers (lin_rs.h, all three tile shapes, with the K-split tail workgroups of a 16 x ~1025-keypoint batch) and the
+    register-streaming attention (attn_rs.h, both ring depths).  Same function, other summation orders."""
+    from dani_slam_amd import frontend
+    w = dict(sp_weights); w.update(lg_weights)
+    e = frontend.Engine(device=0, weights=w, max_batch=8)
+    sizes = [(1025, 1025), (1026, 1024), (1024, 1025), (1025, 1026), (1000, 1025), (1025, 1001), (1024, 1024), (1027, 1025)]
+    pairs = [synth.matching_pair(170 + i, n0=a, n1=b) for i, (a, b) in enumerate(sizes)]
+    cap = 1028
+    K0 = np.zeros((8, cap, 2), np.float32); D0 = np.zeros((8, cap, 256), np.float32)
+    K1 = np.zeros((8, cap, 2), np.float32); D1 = np.zeros((8, cap, 256), np.float32)
+    for p, (k0, d0, k1, d1, _) in enumerate(pairs):
+        K0[p, :len(k0)] = k0; D0[p, :len(k0)] = d0; K1[p, :len(k1)] = k1; D1[p, :len(k1)] = d1
+    n0 = [a for a, _ in sizes]; n1 = [b for _, b in sizes]
+
+    def run(**opts):
+        for k, v in {**dict(lin_rs=-1, attn=0), **opts}.items():
+            e.lg_set_kernel_option(k, v)
+        return e.lg_match_batch(K0, D0, n0, K1, D1, n1, SIZE, SIZE, 0.05)
+    try:
+        base = run(lin_rs=0, attn=2)                                   # round 2's kernels: linear_fm_kernel, attn_kernel<4>
+        assert min(len(m) for m, _ in base) > 300
+        variants = dict(default=run(), lin_tile_1=run(lin_rs=1), lin_tile_2=run(lin_rs=2), attn_ring_4=run(attn=7),
+                        only_linear=run(attn=2), only_attention=run(lin_rs=0))
+        for tag, res in variants.items():
+            for p in range(8):
+                a = {tuple(x): v for x, v in zip(base[p][0].tolist(), base[p][1])}
+                b = {tuple(x): v for x, v in zip(res[p][0].tolist(), res[p][1])}
+                common = set(a) & set(b)
+                assert len(common) >= max(len(a), len(b)) - 2, (tag, p, len(a), len(b))      # a near-tie may flip, nothing more
+                assert max(abs(a[c] - b[c]) for c in common) < 1e-4, (tag, p)
+        # ... and the default form against the oracle itself on two ragged pairs
+        for p in (0, 3):
+            k0, d0, k1, d1, _ = pairs[p]
+            mo, so = lg.match_descriptors(lg_weights, k0, d0, k1, d1, SIZE, SIZE, 0.05)
+            want = {tuple(x): float(v) for x, v in zip(mo.tolist(), so)}
+            got = {tuple(x): float(v) for x, v in zip(variants["default"][p][0].tolist(), variants["default"][p][1])}
+            assert len(set(got) ^ set(want)) <= max(2, len(want) // 100), (p, len(got), len(want))
+            assert max(abs(got[k] - want[k]) for k in set(got) & set(want)) < 1e-3, p
+    finally:
+        for k, v in dict(lin_rs=-1, attn=0).items():
+            e.lg_set_kernel_option(k, v)
+        e.close()
+
