@@ -31,6 +31,9 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
   int bx, head, bz;
   const int tail_q = attn_role(tail_slots, bx, head, bz);
   const LgSet st = sets[bz];
+#ifdef ARS_SKIP_TAILQ   // probe builds only (tools/probes/attn_bench): what the launch costs without its tail-query workgroups
+  if (tail_q >= 0) return;
+#endif
   if (tail_q >= 0) { attn_tail_query(Q, K, V, O, ld, st, tail_q, head, cross, scale, sXch); return; }
   const int mp = (st.nmain + 31) & ~31;
   if (bx * 128 >= mp) return;
@@ -44,14 +47,17 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
   const int ntail = ks.n - ks.nmain;
   // tail keys go to LDS now and are read after the key loop, behind the kernel's only barrier: no wave waits for them here
   if (ntail > 0) attn_stage_tail_keys(K + (size_t)head * 64 * ld, V + (size_t)head * 64 * ld, ld, ks.tail_off, ntail, sTK);
+#ifndef ARS_NO_PRIO
+  // main waves outrank the tail-query workgroups that share their SIMDs (priority, then age, decides every issue slot): the
+  // tail queries' vector instructions then take the slots the MFMA stream leaves free instead of delaying it
+  __builtin_amdgcn_s_setprio(2);
+#endif
   const int q0 = bx * 128 + wave * 32;
   const bool active = q0 < mp;                               // wave-uniform; an idle wave still joins the barrier below
   const int qi = q0 + j;                                     // < mp: query blocks are whole (mp is a multiple of 32)
   const int qtok = st.tok_off + (active ? qi : 0);
 
   float qreg[32];
-#pragma unroll
-  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * (scale * 1.44269504088896341f);
   f32x16 o[2], s[4];
 #pragma unroll
   for (int r = 0; r < 16; r++) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
@@ -143,6 +149,11 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
     auto first = [&](auto t_c) { if constexpr (decltype(t_c)::value < RD) issue(t_c, t_c); };
     first(std::integral_constant<int, 0>()); first(std::integral_constant<int, 1>()); first(std::integral_constant<int, 2>()); first(std::integral_constant<int, 3>());
     first(std::integral_constant<int, 4>()); first(std::integral_constant<int, 5>()); first(std::integral_constant<int, 6>()); first(std::integral_constant<int, 7>());
+  }
+  // the queries are loaded BEHIND the ring's first key operands: one memory round trip in front of the first MFMA, not two
+#pragma unroll
+  for (int t = 0; t < 32; t++) qreg[t] = Qh[(size_t)(2 * t + h) * ld + qtok] * (scale * 1.44269504088896341f);
+  if (nst > 0 && active) {
     // one super-tile: 32 K steps, softmax, 32 V steps.  Instantiated twice: the ragged last tile of a key set carries the
     // key mask, the full tiles carry no trace of it (as one body hipcc turns the mask into 64 selects on 64 precomputed lane
     // masks -- 128 scalar registers, spilled and reloaded in every tile)

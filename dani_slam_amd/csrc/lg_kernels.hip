@@ -1430,12 +1430,13 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
   else if (g_attn_force != 1 && (g_attn_force == 2 || g_attn_force == 6 || g_attn_force == 7 || ((max_mp + 127) / 128) * 4 * nsets >= 512)) {
     // register-streaming form (attn_rs.h) unless DANI_ATTN_RS=0 or the probe asks for the LDS-tiled kernel (force 2)
     static const bool rs_off = getenv("DANI_ATTN_RS") && atoi(getenv("DANI_ATTN_RS")) == 0;
+    static const int rs_tail_sign = getenv("DANI_ATTN_RS_TAIL_FIRST") ? -1 : 1;   // probe knob: tail-query workgroups first in dispatch order
     if (g_attn_force == 6 || (g_attn_force == 0 && !rs_off))
       // ring of 8 loads, 2 waves per SIMD: equal to the ring of 4 at 3 waves per SIMD without tail queries, 2-3 us faster with
       // them (tools/probes/attn_bench.hip, profiles/r03_attn_rs_probe.txt; force 7 = the ring of 4)
-      hipLaunchKernelGGL(attn_rs_kernel<8>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+      hipLaunchKernelGGL(attn_rs_kernel<8>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, rs_tail_sign * max_tail, cross, scale);
     else if (g_attn_force == 7)
-      hipLaunchKernelGGL(attn_rs_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
+      hipLaunchKernelGGL(attn_rs_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, rs_tail_sign * max_tail, cross, scale);
     else
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   }

@@ -128,14 +128,6 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : (NCB == 2 ? 2 : 1)) void linear
   const int K = a.K0 + a.K1, nq = K / 8;
 
   rs_f32x16 acc[NCB][4];
-#pragma unroll
-  for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float bv = a.bias[out0 + cb * 32 + rs_acc_row(r, h)];
-#pragma unroll
-      for (int m = 0; m < 4; m++) acc[cb][m][r] = bv;
-    }
   const unsigned aoff = (unsigned)lane * 16u;
   const unsigned boff = ((unsigned)h * (unsigned)a.ld + (unsigned)t4) * 4u;
   const float* xs1 = a.x1 - (size_t)a.K0 * a.ld;   // row k >= K0 of the concatenation is xs1 + k * ld
@@ -177,6 +169,16 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : (NCB == 2 ? 2 : 1)) void linear
     for (int i = 0; i < 4; i++) load_b(s, s, i);
     load_a(s, s);
   }
+  // the accumulators start from the bias; its loads go out BEHIND the ring's first operands, so that the wave waits for one
+  // memory round trip before its first MFMA, not for two in a row
+#pragma unroll
+  for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float bv = a.bias[out0 + cb * 32 + rs_acc_row(r, h)];
+#pragma unroll
+      for (int m = 0; m < 4; m++) acc[cb][m][r] = bv;
+    }
   int q0 = 0;
   for (; q0 + UQ < nq; q0 += UQ) {
 #pragma unroll
@@ -244,7 +246,11 @@ __global__ __launch_bounds__(256, NCB == 1 ? 3 : (NCB == 2 ? 2 : 1)) void linear
         v0 *= a.alpha; v1 *= a.alpha;
         if (a.res) { v0 += rv[i]; v1 += rv[i + 1]; }
         float* yp = a.y + (size_t)rr * a.ld + t4;
+#ifdef RS_SKIP_STORES   // probe builds only (tools/probes/lin_bench): the launch without its store tail
+        asm volatile("" :: "v"(v0), "v"(v1), "v"(yp));
+#else
         *reinterpret_cast<rs_f32x4*>(yp) = v0; *reinterpret_cast<rs_f32x4*>(yp + a.ld) = v1;
+#endif
       }
     }
   }
