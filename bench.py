@@ -206,6 +206,7 @@ def main():
 
     import threading
     NSEQ = max(1, args.sequences) if cfg == 4 else 1
+    STAGGER_MS = float(os.environ.get("DANI_BENCH_STAGGER_MS", "0"))
     PROF_EVERY = 20
     # N > 1: the batch is ONE sequence of consecutive frames sharded over the ranks (BASELINE config #4), so the pair
     # (last frame of rank r-1, first frame of rank r) crosses a GPU boundary: extract -> all-gather of every rank's last
@@ -292,6 +293,8 @@ def main():
 
         def worker(seq):
             try:
+                if seq and STAGGER_MS > 0:        # sequence q starts q * STAGGER_MS late: its SuperPoint / YOLO phase then runs beside
+                    time.sleep(seq * STAGGER_MS * 1e-3)   # the other sequence's LightGlue instead of beside its SuperPoint / YOLO phase
                 for it in range(total // NSEQ + (1 if seq < total % NSEQ else 0)):
                     # per-kernel HIP-event timing costs ~0.4 ms per step (166 events): sample every PROF_EVERY-th step
                     sample = collect and mode == 4 and it % PROF_EVERY == min(PROF_EVERY, total // NSEQ) // 2

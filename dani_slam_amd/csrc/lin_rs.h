@@ -287,7 +287,11 @@ inline bool launch_linear_rs(int ncb, const LinRsArgs& a0, hipStream_t s) {   //
   if (g == 0) return true;
   if (ncb == 1) hipLaunchKernelGGL((linear_rs_kernel<1, 4>), dim3(g), dim3(256), 0, s, a);
   else if (ncb == 2) hipLaunchKernelGGL((linear_rs_kernel<2, 4>), dim3(g), dim3(256), 0, s, a);
-  else if (ncb == 3) hipLaunchKernelGGL((linear_rs_kernel<3, 2>), dim3(g), dim3(256), 0, s, a);
+  else if (ncb == 3) {
+    static const int uq3 = getenv("DANI_LIN_RS_UQ3") ? atoi(getenv("DANI_LIN_RS_UQ3")) : 2;   // probe knob: ring depth of the 96-output tile
+    if (uq3 == 4) hipLaunchKernelGGL((linear_rs_kernel<3, 4>), dim3(g), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((linear_rs_kernel<3, 2>), dim3(g), dim3(256), 0, s, a);
+  }
   else return false;
   return true;
 }
