@@ -14,9 +14,9 @@
 //     attn_kernel); k-pair (m, r) pairs the keys 4 acc_row(r, 0) + m and 4 acc_row(r, 1) + m, so the A operand of
 //     (m = 0..3, r) is ONE 16-byte load of lane (d, h) at key offset 4 acc_row(r, h); four consecutive r consume one
 //     128-byte line of each of the 32 d rows completely.
-//   * ring of RD (4) x 16 bytes per lane, refilled right behind the MFMAs that consumed a slot (inline asm loads, waits
-//     counted by hand: hipcc would rotate a ring of plain loads into load / wait / use); 64 loads and 256 MFMAs per
-//     super-tile and wave.
+//   * ring of RD x 16 bytes per lane (RD = 8 as shipped, 2 waves per SIMD; RD = 4 fits 3 waves per SIMD and is no faster),
+//     refilled right behind the MFMAs that consumed a slot (inline asm loads, waits counted by hand: hipcc would rotate
+//     a ring of plain loads into load / wait / use); 64 loads and 256 MFMAs per super-tile and wave.
 //   * wave = 32 queries (2 waves per SIMD: one wave's softmax runs under the other's MFMAs); the four waves of a workgroup
 //     are four query blocks of ONE (set, head), so K / V lines are shared in the CU's L1 while the waves stay close.
 #pragma once
@@ -47,6 +47,10 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
   const int ntail = ks.n - ks.nmain;
   // tail keys go to LDS now and are read after the key loop, behind the kernel's only barrier: no wave waits for them here
   if (ntail > 0) attn_stage_tail_keys(K + (size_t)head * 64 * ld, V + (size_t)head * 64 * ld, ld, ks.tail_off, ntail, sTK);
+#ifdef ARS_STAGGER   // probe: the second workgroup of a CU starts ARS_STAGGER * 64 cycles late, so that the two waves of a SIMD
+  // do not reach their softmax (a serial vector chain, no MFMAs) at the same time
+  if (((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) >> 8) & 1) __builtin_amdgcn_s_sleep(ARS_STAGGER);
+#endif
 #ifndef ARS_NO_PRIO
   // main waves outrank the tail-query workgroups that share their SIMDs (priority, then age, decides every issue slot): the
   // tail queries' vector instructions then take the slots the MFMA stream leaves free instead of delaying it

@@ -7,7 +7,7 @@
 // workgroup barrier, no lock-step between the waves of a CU.  linear_fm_kernel spends ~20 % of a K = 256 layer outside its
 // MFMA loop (two barriers per 64-row chunk, staging, and every workgroup of a one-round launch in its prologue at once);
 // this form measured 18-27 % less time per launch on the LightGlue shapes at 16 k tokens (tools/probes/lin_bench.hip,
-// profiles/r03_lin_rs_*.txt).
+// profiles/r03_lin_rs_probe.txt).
 //
 //   * B operand, 16 bytes per lane: lane (j, h) loads tokens 4j .. 4j+3 of row 2p + h.  Element m of that load is the B
 //     operand of token block m, where block m holds the tokens 4j + m of a 128-token tile (four blocks interleaved by
