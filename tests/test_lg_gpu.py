@@ -277,7 +277,8 @@ def test_register_streaming_kernels_match_the_lds_tiled_ones(lg_weights, sp_weig
         base = run(lin_rs=0, attn=2)                                   # round 2's kernels: linear_fm_kernel, attn_kernel<4>
         assert min(len(m) for m, _ in base) > 300
         variants = dict(default=run(), lin_tile_1=run(lin_rs=1), lin_tile_2=run(lin_rs=2), attn_ring_4=run(attn=7),
-                        only_linear=run(attn=2), only_attention=run(lin_rs=0))
+                        only_linear=run(attn=2), only_attention=run(lin_rs=0),
+                        lin_all_k_split_blocks=run(lin_rs=4))          # every token through linear_rs_tail's 32 x 32 blocks
         base_b = run(args_b, lin_rs=0, attn=2)
         assert min(len(m) for m, _ in base_b) > 300
         variants_b = dict(default=run(args_b), lin_tile_1=run(args_b, lin_rs=1), attn_ring_4=run(args_b, attn=7))
