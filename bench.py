@@ -166,6 +166,9 @@ def main():
                     help="N = 1 only: take the N > 1 code path (extract, export of the last frame's features on the device, "
                          "match against the carried slab) to price the split call on one GPU")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra bf16x3 / batch-1 measurements (profiling runs)")
+    ap.add_argument("--host-wait", choices=("spin", "block"), default="spin",
+                    help="how the calling thread waits for the GPU inside the engine (dani_set_host_wait): spin = poll hipStreamQuery "
+                         "(default here: a throughput run has a core to spare per rank; 0.08 ms per step), block = the library's default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,6 +204,7 @@ def main():
     weights = synth.bench_weights()
     eng = frontend.Engine(device=local_rank, max_batch=max(B, 2), max_width=W, max_height=H, weights=weights)
     eng.yolo_set_classes(synth.COCO_NAMES, synth.DYNAMIC_NAMES)   # coco.names is not shipped by the reference
+    eng.set_host_wait(args.host_wait == "spin")
     if args.lg_gemm != "f32":
         eng.lg_set_gemm(eng.LG_GEMM_BF16X3 if args.lg_gemm == "bf16x3" else eng.LG_GEMM_BF16X3_ALL)
 
@@ -428,6 +432,7 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.lg_gemm == "f32" else f"f32 (LightGlue matrix products: {args.lg_gemm} operand split on the bf16 MFMA, f32 accumulate)", "data": "synthetic" + (" (frames handed over as HOST buffers: PCIe-inclusive)" if args.host_inputs else ""),
+            "host_wait": args.host_wait + (" (dani_set_host_wait(1): the calling thread polls hipStreamQuery instead of sleeping in hipStreamSynchronize)" if args.host_wait == "spin" else ""),
             "step_ms": {"median": pct(step_ms, 50), "p10": pct(step_ms, 10), "p90": pct(step_ms, 90), "min": pct(step_ms, 0), "max": pct(step_ms, 100),
                         "n": len(step_ms), "what": "wall time of every dani_frontend_batch call of the timed region on rank 0 (all sequences)",
                         "slow_steps": [[i, round(x, 2)] for i, x in enumerate(step_ms) if x > pct(step_ms, 50) + 0.3][:24]},

@@ -11,6 +11,7 @@ using namespace dani::eng;
 namespace dani {
 namespace eng {
 
+std::atomic<int> g_host_wait{-1};
 thread_local std::string g_create_error;
 // Error text is kept per calling thread (several host threads share one engine: stereo extractors, mapping threads):
 // the message of this thread's last failed call, tagged with the engine it belongs to; e->err (under err_mu) keeps the
@@ -121,6 +122,12 @@ void free_buffers(Context* c) {
 
 // ================================================================================================
 extern "C" {
+
+int dani_set_host_wait(int32_t mode) {
+  if (mode < 0 || mode > 1) return DANI_ERR_INVALID;
+  dani::eng::g_host_wait.store(mode, std::memory_order_relaxed);
+  return DANI_OK;
+}
 
 const char* dani_version(void) { return "dani-frontend-hip 0.1 (gfx950)"; }
 

@@ -77,6 +77,7 @@ def load_library():
     lib.dani_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.dani_lg_set_gemm.argtypes = [C.c_void_p, C.c_int32]
     lib.dani_lg_set_kernel_option.argtypes = [C.c_char_p, C.c_int32]
+    lib.dani_set_host_wait.argtypes = [C.c_int32]
     lib.dani_layer_timings.argtypes = [C.c_void_p, _f]
     lib.dani_last_timings.argtypes = [C.c_void_p, _f, C.c_int32]
     lib.dani_sp_extract_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -397,6 +398,10 @@ class Engine:
                                                   _ip(off1), _ip(i1), _fp(s0) if s0 is not None else None,
                                                   _fp(s1) if s1 is not None else None, C.c_float(threshold), _ip(m), _fp(sc), _ip(mo), cap))
         return [(m[mo[g]:mo[g + 1]].copy(), sc[mo[g]:mo[g + 1]].copy()) for g in range(G)]
+
+    def set_host_wait(self, spin):
+        """Process-wide: the calling thread spins on hipStreamQuery (True) or blocks in hipStreamSynchronize (False, default)."""
+        self._check(self.lib.dani_set_host_wait(1 if spin else 0))
 
     def lg_set_kernel_option(self, name, value):
         """Process-wide kernel selection of the f32 LightGlue path (dani_lg_set_kernel_option): 'lin_rs', 'attn'."""

@@ -153,6 +153,10 @@ DANI_API int dani_lg_set_gemm(dani_engine* e, int32_t mode);
  *   "attn"       0 = per shape (default), 2 = LDS-tiled attn_kernel<4>, 6 / 7 = attn_rs_kernel with a ring of 8 / 4 loads
  * Returns DANI_ERR_INVALID for an unknown name. */
 DANI_API int dani_lg_set_kernel_option(const char* name, int32_t value);
+/* How the calling thread waits for the GPU inside every entry point, process-wide: 0 = block in hipStreamSynchronize (default:
+ * a tracker shares its cores with the mapping threads), 1 = spin on hipStreamQuery (no wake-up latency behind the last kernel
+ * of a phase: 0.08 ms per 8-frame front-end call, at the price of one busy core per calling thread; bench.py uses it). */
+DANI_API int dani_set_host_wait(int32_t mode);
 
 /* Replaces LightGlue::matchDescriptors + normalizeKeypoints + filterMatches (src/LightGlue.cpp:18-122), as
  * called from Frame::ComputeStereoMatches (src/Frame.cc:860), LGmatcher::SearchByBoW (src/LGmatcher.cpp:314) and
