@@ -522,10 +522,11 @@ class Engine:
                                           _ip(o["boxes"]), box_cap, _ip(o["nb"]), _ip(o["m"]), _fp(o["sc"]), mcap, _ip(o["ko"]))
         self._check(rc)
         res = []
+        ns, nbs, ks, monos = o["n"].tolist(), o["nb"].tolist(), (o["ko"].tolist() if match_previous else [0] * B), o["mono"].tolist()
         for b in range(B):
-            n, nb, k = int(o["n"][b]), int(o["nb"][b]), int(o["ko"][b]) if match_previous else 0
+            n, nb, k = ns[b], nbs[b], ks[b]
             res.append(dict(kpts=o["k"][b, :n], resp=o["r"][b, :n], desc=o["d"][b, :n] if want_desc else None,
-                            mono_index=int(o["mono"][b]), boxes=o["boxes"][b, :nb], matches=o["m"][b, :k], scores=o["sc"][b, :k]))
+                            mono_index=monos[b], boxes=o["boxes"][b, :nb], matches=o["m"][b, :k], scores=o["sc"][b, :k]))
         if copy:
             res = [{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in r.items()} for r in res]
         return res
