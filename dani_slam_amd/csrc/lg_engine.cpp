@@ -1,4 +1,5 @@
 // lg_engine.cpp -- LightGlue part of the C ABI (weights packing/folding, workspaces, forward pass, match filter).
+#include <atomic>
 #include "engine_internal.h"
 
 using namespace dani;
@@ -7,7 +8,7 @@ using namespace dani::eng;
 // ================================================================================================
 // LightGlue
 // ================================================================================================
-namespace dani { extern int g_lin_force_rs, g_attn_force; }
+namespace dani { extern std::atomic<int> g_lin_force_rs, g_attn_force; }
 namespace dani {
 namespace eng {
 

@@ -19,6 +19,7 @@
 // for, and with whole-block padding that single keypoint cost every launch a third, almost empty round of workgroups
 // (1088 instead of 1024 on 512 slots: attention 193 us instead of 150 us per launch at 16 x 1025 keypoints).
 #include "common.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -230,11 +231,11 @@ __global__ __launch_bounds__(256, 2) void linear_fm_kernel(LinArgs a) {
   LIN_TRACE(3);
 }
 
-int g_lin_force_tt = 0;   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = the 64-token tile)
+std::atomic<int> g_lin_force_tt{0};   // tuning hook of tools/probes/lin_bench.hip: force the token tile (0 = the 64-token tile)
 
 void pack_linear_rs_host(const float* w_row_major, int out, int in, float* dst) { pack_linear_rs(w_row_major, out, in, dst); }
 
-int g_lin_force_rs = -1;  // tuning hook: -1 = choose per shape (linear_rs_choose), 0 = never, 1..3 = linear_rs_kernel with that NCB
+std::atomic<int> g_lin_force_rs{-1};  // tuning hook: -1 = choose per shape (linear_rs_choose), 0 = never, 1..3 = linear_rs_kernel with that NCB
 
 bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const float* w_packed, const float* bias_packed,
                       float* y, int OUT, int T, int ld, const float* res, const float* cosb, const float* sinb,
@@ -242,8 +243,9 @@ bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   if (OUT % 64 || rot_rows % 64 || (size_t)OUT * ld >= ((size_t)1 << 30)) return false;   // contract of lin_epilogue.h: refused, not launched
   // register-streaming form (lin_rs.h) where the grid it gives fills the chip at least as well as the LDS-tiled one
   static const int rs_env = getenv("DANI_LIN_RS") ? atoi(getenv("DANI_LIN_RS")) : -1;
-  const int rs_mode = g_lin_force_rs >= 0 ? g_lin_force_rs : rs_env;
-  if (w_rs && rs_mode != 0 && g_lin_force_tt == 0) {
+  const int force_rs = g_lin_force_rs.load(std::memory_order_relaxed), force_tt = g_lin_force_tt.load(std::memory_order_relaxed);   // one read per launch (dani_lg_set_kernel_option may run on another thread)
+  const int rs_mode = force_rs >= 0 ? force_rs : rs_env;
+  if (w_rs && rs_mode != 0 && force_tt == 0) {
     const int ncb = rs_mode > 0 ? rs_mode : linear_rs_choose(OUT, K0 + K1, T, ld);
     if (ncb > 0) {
       LinRsArgs r;
@@ -262,8 +264,8 @@ bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
   // 48 KB, 3 per CU) on every LightGlue shape from 16 k to 66 k tokens by 7-17 % (tools/probes/lin_bench.hip), so it is
   // always used; the larger instantiations stay reachable through the probe's tuning hook.
   auto grid = [&](int tt) { return dim3((unsigned)(((T + tt - 1) / tt + 7) / 8 * 8 * otiles)); };   // see the kernel: 8 XCDs
-  if (g_lin_force_tt == 256) hipLaunchKernelGGL(linear_fm_kernel<256>, grid(256), dim3(256), 0, s, a);
-  else if (g_lin_force_tt == 128) hipLaunchKernelGGL(linear_fm_kernel<128>, grid(128), dim3(256), 0, s, a);
+  if (force_tt == 256) hipLaunchKernelGGL(linear_fm_kernel<256>, grid(256), dim3(256), 0, s, a);
+  else if (force_tt == 128) hipLaunchKernelGGL(linear_fm_kernel<128>, grid(128), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(linear_fm_kernel<64>, grid(64), dim3(256), 0, s, a);
   return true;
 }
@@ -1415,33 +1417,34 @@ __global__ __launch_bounds__(256, 2) void attn_x3w_kernel(const float* Q, const 
 #include "attn_rs.h"
 namespace dani {
 
-int g_attn_force = 0;   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel, 4 = attn_x3w_kernel, 5 = attn_k4_kernel, 6 = attn_rs_kernel
+std::atomic<int> g_attn_force{0};   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel, 4 = attn_x3w_kernel, 5 = attn_k4_kernel, 6 = attn_rs_kernel
 
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_mp, int max_tail, int cross, float scale, hipStream_t s, int x3) {
+  const int force = g_attn_force.load(std::memory_order_relaxed);   // one read per launch (dani_lg_set_kernel_option may run on another thread)
   // grid.x: query tiles of the main regions + max_tail slots per (head, set) for the tail-query workgroups (attn_role)
-  if ((x3 && g_attn_force == 0 && ((max_mp + 127) / 128) * 4 * nsets >= 512) || g_attn_force == 4)   // as for the f32 pair below
+  if ((x3 && force == 0 && ((max_mp + 127) / 128) * 4 * nsets >= 512) || force == 4)   // as for the f32 pair below
     hipLaunchKernelGGL(attn_x3w_kernel, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
-  else if (x3 || g_attn_force == 3)
+  else if (x3 || force == 3)
     hipLaunchKernelGGL(attn_x3_kernel, dim3((max_mp + 63) / 64 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   // 128-query workgroups (no key split, half the tile staging per MFMA, no merge) once they fill the chip's 512 resident
   // slots in whole rounds; below that the key-split kernel's twice as many, half as long workgroups balance better.
   // At 16 x 1025 keypoints (512 workgroups = one round): 150.1 vs 156.0 us (tools/probes/attn_bench.hip).
-  else if (g_attn_force != 1 && (g_attn_force == 2 || g_attn_force == 6 || g_attn_force == 7 || ((max_mp + 127) / 128) * 4 * nsets >= 512)) {
+  else if (force != 1 && (force == 2 || force == 6 || force == 7 || ((max_mp + 127) / 128) * 4 * nsets >= 512)) {
     // register-streaming form (attn_rs.h) unless DANI_ATTN_RS=0 or the probe asks for the LDS-tiled kernel (force 2)
     static const bool rs_off = getenv("DANI_ATTN_RS") && atoi(getenv("DANI_ATTN_RS")) == 0;
     static const int rs_tail_sign = getenv("DANI_ATTN_RS_TAIL_FIRST") ? -1 : 1;   // probe knob: tail-query workgroups first in dispatch order
-    if (g_attn_force == 6 || (g_attn_force == 0 && !rs_off))
+    if (force == 6 || (force == 0 && !rs_off))
       // ring of 8 loads, 2 waves per SIMD: equal to the ring of 4 at 3 waves per SIMD without tail queries, 2-3 us faster with
       // them (tools/probes/attn_bench.hip, profiles/r03_attn_rs_probe.txt; force 7 = the ring of 4)
       hipLaunchKernelGGL(attn_rs_kernel<8>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, rs_tail_sign * max_tail, cross, scale);
-    else if (g_attn_force == 7)
+    else if (force == 7)
       hipLaunchKernelGGL(attn_rs_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, rs_tail_sign * max_tail, cross, scale);
     else
     hipLaunchKernelGGL(attn_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, max_tail, cross, scale);
   }
   // fewer key-split workgroups than CUs (one pair of 1024 keypoints: 136): four key quarters per 32-query block instead
-  else if (g_attn_force == 5 || (g_attn_force == 0 && ((max_mp + 63) / 64) * 4 * nsets <= 256)) {
+  else if (force == 5 || (force == 0 && ((max_mp + 63) / 64) * 4 * nsets <= 256)) {
     static bool attr_set_dev[64] = {};   // per device; idempotent: a race between two first callers sets the same values twice
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
