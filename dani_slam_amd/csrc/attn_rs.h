@@ -22,6 +22,9 @@
 #pragma once
 
 namespace dani {
+#ifdef ARS_CLOCK
+__device__ unsigned long long g_ars_clock[2];
+#endif
 
 template <int RD>   // ring depth: 16-byte operand loads in flight per wave
 __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const float* Q, const float* K, const float* V, float* O, int ld,
@@ -37,6 +40,9 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
   if (tail_q >= 0) { attn_tail_query(Q, K, V, O, ld, st, tail_q, head, cross, scale, sXch); return; }
   const int mp = (st.nmain + 31) & ~31;
   if (bx * 128 >= mp) return;
+#ifdef ARS_CLOCK   // probe: core clock while the launch runs (s_memtime counts core cycles, s_memrealtime 100 MHz)
+  const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const AttnKeys ks = attn_keys(st, cross);
@@ -153,6 +159,8 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
     auto first = [&](auto t_c) { if constexpr (decltype(t_c)::value < RD) issue(t_c, t_c); };
     first(std::integral_constant<int, 0>()); first(std::integral_constant<int, 1>()); first(std::integral_constant<int, 2>()); first(std::integral_constant<int, 3>());
     first(std::integral_constant<int, 4>()); first(std::integral_constant<int, 5>()); first(std::integral_constant<int, 6>()); first(std::integral_constant<int, 7>());
+    first(std::integral_constant<int, 8>()); first(std::integral_constant<int, 9>()); first(std::integral_constant<int, 10>()); first(std::integral_constant<int, 11>());
+    first(std::integral_constant<int, 12>()); first(std::integral_constant<int, 13>()); first(std::integral_constant<int, 14>()); first(std::integral_constant<int, 15>());
   }
   // the queries are loaded BEHIND the ring's first key operands: one memory round trip in front of the first MFMA, not two
 #pragma unroll
@@ -174,15 +182,27 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
     };
     const int nfull = k_n / 128;
     for (int stile = 0; stile < nfull; stile++) {
+#ifdef ARS_PRIO_PROGRESS   // probe: issue priority falls with a wave's progress, so that the younger wave of a SIMD catches up
+      switch ((stile * 4) / nst) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+      }
+#endif
       int sn = min(stile + 1, nst - 1);   // the last super-tile refills with its own addresses again (loaded, never used)
       asm volatile("" : "+s"(sn));
       tile(std::false_type(), stile, sn);
     }
     if (nfull < nst) tile(std::true_type(), nfull, nfull);
     // the refills of the last super-tile are still in flight: nothing may reuse their registers before they have landed
-    if constexpr (RD == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[3]), "+v"(rg[4]), "+v"(rg[5]), "+v"(rg[6]), "+v"(rg[RD - 1]));
+    if constexpr (RD == 16) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[3]), "+v"(rg[4]), "+v"(rg[5]), "+v"(rg[6]), "+v"(rg[7]));
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(rg[8]), "+v"(rg[9]), "+v"(rg[10]), "+v"(rg[11]), "+v"(rg[12]), "+v"(rg[13]), "+v"(rg[14]), "+v"(rg[RD - 1]));
+    }
+    else if constexpr (RD == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[3]), "+v"(rg[4]), "+v"(rg[5]), "+v"(rg[6]), "+v"(rg[RD - 1]));
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rg[0]), "+v"(rg[1]), "+v"(rg[2]), "+v"(rg[RD - 1]));
-    static_assert(RD == 4 || RD == 8, "ring depth");
+    static_assert(RD == 4 || RD == 8 || RD == 16, "ring depth");
   }
 #undef ARS_STEPS8
   // everything below is re-derived from the set record instead of being kept live across the key loop (registers)
@@ -204,6 +224,11 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
   for (int db = 0; db < 2; db++)
 #pragma unroll
     for (int r = 0; r < 16; r++) Oh[(size_t)(db * 32 + acc_row(r, h)) * ld] = qi2 < st2.nmain ? o[db][r] * keep : 0.0f;
+#ifdef ARS_CLOCK
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    g_ars_clock[0] = __builtin_amdgcn_s_memtime() - ck0; g_ars_clock[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 }
 
 }  // namespace dani

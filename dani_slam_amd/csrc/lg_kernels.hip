@@ -1430,7 +1430,7 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
   // 128-query workgroups (no key split, half the tile staging per MFMA, no merge) once they fill the chip's 512 resident
   // slots in whole rounds; below that the key-split kernel's twice as many, half as long workgroups balance better.
   // At 16 x 1025 keypoints (512 workgroups = one round): 150.1 vs 156.0 us (tools/probes/attn_bench.hip).
-  else if (force != 1 && (force == 2 || force == 6 || force == 7 || ((max_mp + 127) / 128) * 4 * nsets >= 512)) {
+  else if (force != 1 && (force == 2 || force == 6 || force == 7 || force == 8 || ((max_mp + 127) / 128) * 4 * nsets >= 512)) {
     // register-streaming form (attn_rs.h) unless DANI_ATTN_RS=0 or the probe asks for the LDS-tiled kernel (force 2)
     static const bool rs_off = getenv("DANI_ATTN_RS") && atoi(getenv("DANI_ATTN_RS")) == 0;
     static const int rs_tail_sign = getenv("DANI_ATTN_RS_TAIL_FIRST") ? -1 : 1;   // probe knob: tail-query workgroups first in dispatch order
@@ -1438,6 +1438,8 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
       // ring of 8 loads, 2 waves per SIMD: equal to the ring of 4 at 3 waves per SIMD without tail queries, 2-3 us faster with
       // them (tools/probes/attn_bench.hip, profiles/r03_attn_rs_probe.txt; force 7 = the ring of 4)
       hipLaunchKernelGGL(attn_rs_kernel<8>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, rs_tail_sign * max_tail, cross, scale);
+    else if (force == 8)   // probe: ring of 16 loads
+      hipLaunchKernelGGL(attn_rs_kernel<16>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, rs_tail_sign * max_tail, cross, scale);
     else if (force == 7)
       hipLaunchKernelGGL(attn_rs_kernel<4>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, rs_tail_sign * max_tail, cross, scale);
     else

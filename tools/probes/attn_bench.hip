@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(ds, hs.data(), sizeof(LgSet) * nsets, hipMemcpyHostToDevice));
     const double flops = (double)nsets * 4.0 * 256.0 * n * (double)n;
     if (!warm) { for (int i = 0; i < 200; i++) launch_attention(QKV, QKV + (size_t)256 * ld, QKV + (size_t)512 * ld, O, ld, ds, nsets, max_mp, any_tail, 0, 0.125f, 0); CK(hipDeviceSynchronize()); warm = true; }
-    for (int force : {2, 6, 7})
+    for (int force : {2, 6, 7, 8})
     for (int cross = 0; cross < 2; cross++) {
       g_attn_force = force;
       std::vector<double> us;
@@ -55,8 +55,11 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, a, b));
         us.push_back(ms * 100.0);
       }
+#ifdef ARS_CLOCK
+      if (force == 6) { unsigned long long ck[2]; CK(hipMemcpyFromSymbol(ck, HIP_SYMBOL(dani::g_ars_clock), sizeof(ck))); printf("  workgroup 0: %.1f us at %.3f GHz core clock\n", ck[1] / 100.0, (double)ck[0] / ck[1] / 10.0); }
+#endif
       std::sort(us.begin(), us.end());
-      printf("n=%5d %s kernel %s  main tiles %d any_tail %d   median %7.1f us  min %7.1f   %6.1f TFLOP/s\n", n, cross ? "cross" : "self ", force == 1 ? "ks  " : force == 2 ? "nw4 " : force == 3 ? "x3  " : force == 6 ? "rs8 " : force == 7 ? "rs4 " : "x3w ", max_mp / 64, any_tail,
+      printf("n=%5d %s kernel %s  main tiles %d any_tail %d   median %7.1f us  min %7.1f   %6.1f TFLOP/s\n", n, cross ? "cross" : "self ", force == 1 ? "ks  " : force == 2 ? "nw4 " : force == 3 ? "x3  " : force == 6 ? "rs8 " : force == 7 ? "rs4 " : force == 8 ? "rs16" : "x3w ", max_mp / 64, any_tail,
              us[3], us[0], flops / (us[3] * 1e-6) / 1e12);
     }
   }
