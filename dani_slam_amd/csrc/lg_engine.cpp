@@ -319,7 +319,7 @@ extern "C" {
 int dani_lg_set_kernel_option(const char* name, int32_t value) {
   if (!name) return DANI_ERR_INVALID;
   if (!strcmp(name, "lin_rs")) { if (value < -1 || value > 4) return DANI_ERR_INVALID; dani::g_lin_force_rs = value; return DANI_OK; }
-  if (!strcmp(name, "attn")) { if (value < 0 || value > 7) return DANI_ERR_INVALID; dani::g_attn_force = value; return DANI_OK; }
+  if (!strcmp(name, "attn")) { if (value < 0 || value > 8) return DANI_ERR_INVALID; dani::g_attn_force = value; return DANI_OK; }
   return DANI_ERR_INVALID;
 }
 

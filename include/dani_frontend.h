@@ -150,7 +150,7 @@ DANI_API int dani_lg_set_gemm(dani_engine* e, int32_t mode);
 /* Kernel selection of the f32 LightGlue path, process-wide, for A/B tests and measurements (results agree within the
  * tolerances of DESIGN.md; defaults = the shipped choice).  name:
  *   "lin_rs"    -1 = per shape (default), 0 = LDS-tiled linear_fm_kernel only, 1..3 = linear_rs_kernel with that tile
- *   "attn"       0 = per shape (default), 2 = LDS-tiled attn_kernel<4>, 6 / 7 = attn_rs_kernel with a ring of 8 / 4 loads
+ *   "attn"       0 = per shape (default), 2 = LDS-tiled attn_kernel<4>, 6 / 7 / 8 = attn_rs_kernel with a ring of 8 / 4 / 16 loads
  * Returns DANI_ERR_INVALID for an unknown name. */
 DANI_API int dani_lg_set_kernel_option(const char* name, int32_t value);
 /* How the calling thread waits for the GPU inside every entry point, process-wide: 0 = block in hipStreamSynchronize (default:

@@ -281,7 +281,7 @@ def test_register_streaming_kernels_match_the_lds_tiled_ones(lg_weights, sp_weig
                         lin_all_k_split_blocks=run(lin_rs=4))          # every token through linear_rs_tail's 32 x 32 blocks
         base_b = run(args_b, lin_rs=0, attn=2)
         assert min(len(m) for m, _ in base_b) > 300
-        variants_b = dict(default=run(args_b), lin_tile_1=run(args_b, lin_rs=1), attn_ring_4=run(args_b, attn=7))
+        variants_b = dict(default=run(args_b), lin_tile_1=run(args_b, lin_rs=1), attn_ring_4=run(args_b, attn=7), attn_ring_16=run(args_b, attn=8))
         for tag, res in list(variants.items()) + [(t + "_b", r) for t, r in variants_b.items()]:
             ref = base_b if tag.endswith("_b") else base
             for p in range(len(ref)):
