@@ -88,6 +88,10 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
     constexpr int slot = decltype(slot_c)::value, t = decltype(t_c)::value;
     // (named here, outside the `if constexpr` branches: clang does not capture variables that only a discarded branch uses)
     const float*& kp = kptr; const float* const& vptr0_ = vptr0; const float* const& vptr1_ = vptr1; const unsigned koff_ = koff, voff_ = voff; f32x4& dst = rg[slot];
+#ifdef ARS_NO_LOADS   // probe builds: no operand loads at all (the registers keep what they hold; values meaningless)
+    asm volatile("" : "+v"(dst));
+    return;
+#endif
     if constexpr (t < 32) {
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(koff_), "s"(kp));
       kp += 2 * (size_t)ld;
@@ -177,7 +181,9 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
 #pragma unroll
         for (int r = 0; r < 16; r++) s[mm][r] = 0.0f;
       ARS_STEPS8(0, sn) ARS_STEPS8(8, sn) ARS_STEPS8(16, sn) ARS_STEPS8(24, sn)
+#ifndef ARS_SKIP_SOFTMAX   // probe builds: the launch without its softmax (values meaningless)
       softmax(stile * 128, ragged_c);
+#endif
       ARS_STEPS8(32, sn) ARS_STEPS8(40, sn) ARS_STEPS8(48, sn) ARS_STEPS8(56, sn)
     };
     const int nfull = k_n / 128;
