@@ -182,7 +182,16 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
         for (int r = 0; r < 16; r++) s[mm][r] = 0.0f;
       ARS_STEPS8(0, sn) ARS_STEPS8(8, sn) ARS_STEPS8(16, sn) ARS_STEPS8(24, sn)
 #ifndef ARS_SKIP_SOFTMAX   // probe builds: the launch without its softmax (values meaningless)
+#ifdef ARS_SOFTMAX_LOW_PRIO
+      // the issue arbiter prefers the older wave of a SIMD: while THAT wave is in its softmax (~1800 cycles of back-to-back
+      // vector instructions, no MFMA), the younger wave's MFMAs would wait for a gap that never comes.  At priority 0 the softmax
+      // yields to them (an MFMA takes the port for 4 of its 64 cycles)
+      __builtin_amdgcn_s_setprio(0);
+#endif
       softmax(stile * 128, ragged_c);
+#ifdef ARS_SOFTMAX_LOW_PRIO
+      __builtin_amdgcn_s_setprio(2);
+#endif
 #endif
       ARS_STEPS8(32, sn) ARS_STEPS8(40, sn) ARS_STEPS8(48, sn) ARS_STEPS8(56, sn)
     };
