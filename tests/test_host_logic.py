@@ -110,6 +110,26 @@ def test_malformed_weight_file_is_an_error_code(tmp_path):
     assert lib.dani_load_weights_file(None, b"/nonexistent") == frontend.DANI_ERR_INVALID
 
 
+def test_process_wide_options_validate_their_arguments():
+    """dani_lg_set_kernel_option / dani_set_host_wait touch no device: unknown names and out-of-range values are error codes,
+    the documented values are accepted (and put back)."""
+    lib = frontend.load_library()
+    lib.dani_lg_set_kernel_option.restype = ctypes.c_int
+    lib.dani_lg_set_kernel_option.argtypes = [ctypes.c_char_p, ctypes.c_int32]
+    lib.dani_set_host_wait.restype = ctypes.c_int
+    lib.dani_set_host_wait.argtypes = [ctypes.c_int32]
+    assert lib.dani_lg_set_kernel_option(None, 0) == frontend.DANI_ERR_INVALID
+    assert lib.dani_lg_set_kernel_option(b"no_such_option", 0) == frontend.DANI_ERR_INVALID
+    for name, good, bad in ((b"lin_rs", (-1, 0, 1, 2, 3, 4), (-2, 5)), (b"attn", (0, 2, 6, 7, 8), (-1, 9))):
+        for v in bad:
+            assert lib.dani_lg_set_kernel_option(name, v) == frontend.DANI_ERR_INVALID, (name, v)
+        for v in good:
+            assert lib.dani_lg_set_kernel_option(name, v) == 0, (name, v)
+    assert lib.dani_lg_set_kernel_option(b"lin_rs", -1) == 0 and lib.dani_lg_set_kernel_option(b"attn", 0) == 0   # the defaults
+    assert lib.dani_set_host_wait(7) == frontend.DANI_ERR_INVALID
+    assert lib.dani_set_host_wait(1) == 0 and lib.dani_set_host_wait(0) == 0
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """On a machine without an MI355X the engine must refuse to exist (there is no CPU compute path)."""
     import torch
