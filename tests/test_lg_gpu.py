@@ -258,9 +258,14 @@ def test_register_streaming_kernels_match_the_lds_tiled_ones(lg_weights, sp_weig
     # + 64 (two K-split tail blocks per out block), and key sets whose last 128-key super-tile holds 6 keys (the masked tile body)
     sizes_b = [(1030, 1030)] * 6 + [(1030, 1000)]
 
+    # third batch, forced onto the register-streaming kernels although the launcher would not choose them at this size: unequal
+    # sets (1025 + 1060 + 700 + 1280 keypoints -> 1024 + 1088 + 704 + 1280 + 32 tail tokens = 4128 = 32 tiles of 128 + 32; with
+    # the first pair alone 2144 = 16 tiles + 96), key sets of 5.5 / 8.5 / 10 super-tiles, one tail query and one tail key
+    sizes_c = [(1025, 1060), (700, 1280)]
+
     def batch(sz, seed):
         prs = [synth.matching_pair(seed + i, n0=a, n1=b) for i, (a, b) in enumerate(sz)]
-        cap = 1032
+        cap = max(1032, max(max(a, b) for a, b in sz) + 2)
         K0 = np.zeros((len(sz), cap, 2), np.float32); D0 = np.zeros((len(sz), cap, 256), np.float32)
         K1 = np.zeros((len(sz), cap, 2), np.float32); D1 = np.zeros((len(sz), cap, 256), np.float32)
         for p, (k0, d0, k1, d1, _) in enumerate(prs):
@@ -268,6 +273,8 @@ def test_register_streaming_kernels_match_the_lds_tiled_ones(lg_weights, sp_weig
         return prs, (K0, D0, [a for a, _ in sz], K1, D1, [b for _, b in sz])
     pairs, args_a = batch(sizes, 170)
     _, args_b = batch(sizes_b, 190)
+    _, args_c = batch(sizes_c, 230)
+    args_c1 = tuple(a[:1] for a in args_c)                             # the first pair alone
 
     def run(args=args_a, **opts):
         for k, v in {**dict(lin_rs=-1, attn=0), **opts}.items():
@@ -282,8 +289,14 @@ def test_register_streaming_kernels_match_the_lds_tiled_ones(lg_weights, sp_weig
         base_b = run(args_b, lin_rs=0, attn=2)
         assert min(len(m) for m, _ in base_b) > 300
         variants_b = dict(default=run(args_b), lin_tile_1=run(args_b, lin_rs=1), attn_ring_4=run(args_b, attn=7), attn_ring_16=run(args_b, attn=8))
-        for tag, res in list(variants.items()) + [(t + "_b", r) for t, r in variants_b.items()]:
-            ref = base_b if tag.endswith("_b") else base
+        base_c = run(args_c, lin_rs=0, attn=2); base_c1 = run(args_c1, lin_rs=0, attn=2)
+        assert min(len(m) for m, _ in base_c) > 200
+        variants_c = dict(rs_1=run(args_c, lin_rs=1, attn=6), rs_2=run(args_c, lin_rs=2, attn=8), rs_4=run(args_c, lin_rs=4, attn=7))
+        variants_c1 = dict(rs_1=run(args_c1, lin_rs=1, attn=6), rs_2=run(args_c1, lin_rs=2, attn=6))
+        refs = {"_b": base_b, "_c": base_c, "_c1": base_c1}
+        for tag, res in (list(variants.items()) + [(t + "_b", r) for t, r in variants_b.items()] + [(t + "_c", r) for t, r in variants_c.items()]
+                         + [(t + "_c1", r) for t, r in variants_c1.items()]):
+            ref = next((r for sfx, r in refs.items() if tag.endswith(sfx)), base)
             for p in range(len(ref)):
                 a = {tuple(x): v for x, v in zip(ref[p][0].tolist(), ref[p][1])}
                 b = {tuple(x): v for x, v in zip(res[p][0].tolist(), res[p][1])}
