@@ -300,6 +300,9 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
 int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, int32_t on_device, int32_t B, int32_t W, int32_t H,
                      int32_t stride, float score_thresh, float iou_thresh, float* dets6, int32_t cap, int32_t* n_out);
 void sp_read_timers(Context* c, bool prof);
+// weights_spec.cpp: a tensor set (name -> float count) against the SuperPoint (required) / LightGlue / YOLOv5s (optional groups) specs;
+// msg names the first missing or mis-shaped tensor; *groups: bit 0 SuperPoint, 1 LightGlue, 2 YOLO present
+int check_tensor_counts(const std::map<std::string, size_t>& have, std::string& msg, int* groups, int* ignored);
 int lg_finalize(dani_engine* e);     // pack the LightGlue / YOLO tensors of e->tensors (dani_finalize_weights, sp_engine.cpp)
 int yolo_finalize(dani_engine* e);
 void lg_release(dani_engine* e);     // workspaces and packed weights die with the engine

@@ -148,6 +148,12 @@ extern "C" {
 
 int dani_finalize_weights(dani_engine* e) {
   if (!e) return DANI_ERR_INVALID;
+  {   // every name and shape first, on the host (weights_spec.cpp): the error names the offending tensor
+    std::map<std::string, size_t> have;
+    for (const auto& kv : e->tensors) have[kv.first] = kv.second.size();
+    std::string msg;
+    if (check_tensor_counts(have, msg, nullptr, nullptr) != DANI_OK) return fail(e, DANI_ERR_WEIGHTS, "%s", msg.c_str());
+  }
   HIP_TRY(e, hipSetDevice(e->device));
   for (void* p : e->weight_allocs) (void)hipFree(p);
   e->weight_allocs.clear();

@@ -69,6 +69,13 @@ DANI_API const char* dani_last_error(const dani_engine* e); /* e may be NULL: la
 DANI_API int dani_set_tensor(dani_engine* e, const char* name, const float* data, int64_t count);
 /* Load every tensor of a .dsw container (tools/convert_weights.py). */
 DANI_API int dani_load_weights_file(dani_engine* e, const char* path);
+/* Host-only (no GPU, no engine): check a .dsw container against the tensor names and shapes the engine expects --
+ * SuperPoint's 24 tensors are required (the reference exits when torch::load fails, src/SPextractor.cpp:86-91); the
+ * LightGlue group (public checkpoint names, src/LightGlue.cpp:9) and the YOLOv5s group (fused public names,
+ * src/YoloDetect.cpp:9) must each be absent or complete.  Returns DANI_OK or DANI_ERR_WEIGHTS with `msg` naming the first
+ * missing / mis-shaped tensor; *groups (optional): bit 0 SuperPoint, bit 1 LightGlue, bit 2 YOLOv5s present.  The same
+ * check runs inside dani_finalize_weights.  tools/convert_weights.py calls it on every archive it converts. */
+DANI_API int dani_check_weights_file(const char* path, int32_t* groups, char* msg, int32_t msg_cap);
 /* Called once after the last dani_set_tensor: packs weights into the kernels' layouts. */
 DANI_API int dani_finalize_weights(dani_engine* e);
 

@@ -1,7 +1,8 @@
 """GPU: the exact workload bench.py times -- dani_frontend_batch over B = 8 device-resident 640x480 frames of the
 moving-camera sequence, nFeatures = 1024, YOLO on, two consecutive calls -- against the composition of the three
 oracles.  This is the shape at which the single-level host cull (SpCall::host_cull), the 257th token tile of the linear
-layers, the tail-token paths and the 128-query attention kernels (attn_kernel<4>, attn_x3w_kernel) run in situ; the
+layers (linear_rs_kernel's tail workgroups), the tail-token paths and the 128-query attention kernels (attn_rs_kernel<8>,
+attn_x3w_kernel) run in situ; the
 smaller fused-call tests (tests/test_frontend_gpu.py, nFeatures = 300, B = 2) never reach them."""
 import numpy as np
 import pytest

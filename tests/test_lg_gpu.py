@@ -129,8 +129,9 @@ def test_batch_equals_single(engine, lg_weights):
 
 
 def test_large_batch_kernel_with_ragged_sets(lg_weights, sp_weights):
-    """32 keypoint sets of ~1024 keypoints take the 128-query-tile attention kernel (attn_kernel<4>) instead of the
-    key-split one: its tail-key / tail-query paths (sets of 1025..1028 keypoints) must give what the single-pair path gives."""
+    """32 keypoint sets of ~1024 keypoints take the 128-query-tile attention kernel (512 workgroups and more: the
+    register-streaming attn_rs_kernel<8> since round 3; attn_kernel<4> with dani_lg_set_kernel_option("attn", 2)) instead of
+    the key-split ones: its tail-key / tail-query paths (sets of 1025..1028 keypoints) must give what the single-pair path gives."""
     from dani_slam_amd import frontend
     w = dict(sp_weights); w.update(lg_weights)
     e = frontend.Engine(device=0, weights=w, max_batch=16)
