@@ -41,8 +41,8 @@ W, H = 640, 480
 NFEATURES = 1024
 SP_GFLOP_PER_FRAME = 52.10
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-DOMINANT_LAYERS = (1, 3, 5)       # conv1b, conv2b, conv3b: conv_mfma_kernel<Cfg<3,1,32,2,8,true,true>>
-DOMINANT_KERNEL = "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,pool>> (conv1b+conv2b+conv3b)"
+POOLED_CONV_LAYERS = (1, 3, 5)    # conv1b, conv2b, conv3b: conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,pool>> (third kernel by total time;
+POOLED_CONV_KERNEL = "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,pool>> (conv1b+conv2b+conv3b)"   # the dominant one is linear_rs_kernel)
 
 
 def exact_layer_flops(li, B):
@@ -166,9 +166,10 @@ def main():
                     help="N = 1 only: take the N > 1 code path (extract, export of the last frame's features on the device, "
                          "match against the carried slab) to price the split call on one GPU")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra bf16x3 / batch-1 measurements (profiling runs)")
-    ap.add_argument("--host-wait", choices=("spin", "block"), default="spin",
-                    help="how the calling thread waits for the GPU inside the engine (dani_set_host_wait): spin = poll hipStreamQuery "
-                         "(default here: a throughput run has a core to spare per rank; 0.08 ms per step), block = the library's default")
+    ap.add_argument("--host-wait", choices=("spin", "block"), default="block",
+                    help="how the calling thread waits for the GPU inside the engine (dani_set_host_wait): block = the library's default "
+                         "(the headline uses what a caller gets without asking); spin = poll hipStreamQuery, one busy core per rank, "
+                         "0.08 ms per step less -- a default N = 1 run reports it as the side mode `host_wait_spin`")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -396,6 +397,19 @@ def main():
                          "note": f"dani_lg_set_gemm({key[8:].upper()}): {what} as six bf16 MFMAs over three-term operand splits, "
                                  "f32 accumulation; opt-in, not the headline"}
         eng.lg_set_gemm(eng.LG_GEMM_F32)
+        if args.host_wait == "block":   # the non-default library mode dani_set_host_wait(1), same workload, after the timed region
+            eng.set_host_wait(True)
+            run_steps(20, False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            _, _, _, _, _, sms = run_steps(SIDE_STEPS, False)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t1
+            eng.set_host_wait(False)
+            side["host_wait_spin"] = {"value": round(B * SIDE_STEPS / dts, 3), "unit": "frames/s", "steps": SIDE_STEPS,
+                                      "ms_per_step": round(dts / SIDE_STEPS * 1e3, 4), "ms_per_step_median": pct(sms, 50),
+                                      "note": "dani_set_host_wait(1): the calling thread polls hipStreamQuery instead of sleeping in "
+                                              "hipStreamSynchronize (one busy core per rank); opt-in, not the headline"}
         # BASELINE configs #2 and #3: one call at a time, as a live tracker issues them (src/Frame.cc:420-427, :813-860), on an
         # engine built for that use (max_batch = 2: the engines pick their tile shapes for the batch they are built for)
         lat = {}
@@ -432,14 +446,14 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.lg_gemm == "f32" else f"f32 (LightGlue matrix products: {args.lg_gemm} operand split on the bf16 MFMA, f32 accumulate)", "data": "synthetic" + (" (frames handed over as HOST buffers: PCIe-inclusive)" if args.host_inputs else ""),
-            "host_wait": args.host_wait + (" (dani_set_host_wait(1): the calling thread polls hipStreamQuery instead of sleeping in hipStreamSynchronize)" if args.host_wait == "spin" else ""),
+            "host_wait": args.host_wait + (" (dani_set_host_wait(1): the calling thread polls hipStreamQuery instead of sleeping in hipStreamSynchronize)" if args.host_wait == "spin" else " (the library's default: hipStreamSynchronize)"),
             "step_ms": {"median": pct(step_ms, 50), "p10": pct(step_ms, 10), "p90": pct(step_ms, 90), "min": pct(step_ms, 0), "max": pct(step_ms, 100),
                         "n": len(step_ms), "what": "wall time of every dani_frontend_batch call of the timed region on rank 0 (all sequences)",
                         "slow_steps": [[i, round(x, 2)] for i, x in enumerate(step_ms) if x > pct(step_ms, 50) + 0.3][:24]},
         }
         if cfg == 4:
-            conv_dom_ms = float(sum(layer_ms[i] for i in DOMINANT_LAYERS))
-            conv_dom_flops = sum(exact_layer_flops(i, B) for i in DOMINANT_LAYERS)
+            conv_dom_ms = float(sum(layer_ms[i] for i in POOLED_CONV_LAYERS))
+            conv_dom_flops = sum(exact_layer_flops(i, B) for i in POOLED_CONV_LAYERS)
             conv_achieved = conv_dom_flops / (conv_dom_ms * 1e-3) / 1e12 if conv_dom_ms > 0 else 0.0
             # second kernel by total time: LightGlue attention (18 launches per step)
             attn_ms, attn_flop, attn_launches = float(attn[0]), float(attn[1]), int(round(attn[2]))
@@ -482,10 +496,10 @@ def main():
                                        "achieved": round(attn_achieved, 3), "frac": round(attn_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
                                        "avg_launch_ms": round(attn_ms / max(attn_launches, 1), 4), "launches_per_step": attn_launches,
                                        "algorithmic_gflop_per_step": round(attn_flop / 1e9, 2)},
-                                   DOMINANT_KERNEL: {"achieved": round(conv_achieved, 3),
+                                   POOLED_CONV_KERNEL: {"achieved": round(conv_achieved, 3),
                                                      "frac": round(conv_achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-                                                     "avg_launch_ms": round(conv_dom_ms / len(DOMINANT_LAYERS), 4),
-                                                     "launches_per_step": len(DOMINANT_LAYERS)}}}
+                                                     "avg_launch_ms": round(conv_dom_ms / len(POOLED_CONV_LAYERS), 4),
+                                                     "launches_per_step": len(POOLED_CONV_LAYERS)}}}
             # host wall-clock phases of one call (they overlap device work of the neighbouring phases; NOT device time per network)
             res["stages_ms_per_step"] = {
                 "phase1_enqueue_sp_network_then_wait_for_yolo_boxes": round(float(fe_ms[0]), 3),

@@ -134,10 +134,22 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
     m = m_new;
   };
   // one step: wait for the slot (RD - 1 younger loads may stay in flight), its 4 MFMAs, then refill the slot with step t + RD
-  auto step = [&](auto t_c, int stile_next) {
+  auto step = [&](auto t_c, int stile_next, auto ragged_c) {
     constexpr int t = decltype(t_c)::value, slot = t % RD;
     const float*& kp = kptr; const float (&qr)[32] = qreg; f32x16 (&sa)[4] = s; f32x16 (&oa)[2] = o;
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rg[slot]) : "n"(RD - 1));
+    if constexpr (decltype(ragged_c)::value && t >= 32) {
+      // Ragged last super-tile: the V operands of masked keys (>= k_n: the next set's columns, the tail region or the slack
+      // behind T) are multiplied by P = 0 in the MFMA -- harmless only while they are finite.  A call that produced Inf / NaN
+      // (NaN descriptors, say) leaves them in such columns for every later, smaller batch, and 0 * NaN would then poison the
+      // last set's messages for good.  Zero them in the register (once per wave and launch: 128 selects).
+      const int k_n_ = k_n; const int h_ = h;
+      const int lim = (k_n_ & 127) - 16 * h_;
+      constexpr int r = (t - 32) >> 1;
+#pragma unroll
+      for (int mm = 0; mm < 4; mm++)
+        if (4 * acc_row(r, 0) + mm >= lim) rg[slot][mm] = 0.0f;
+    }
     if constexpr (t < 32) {
 #pragma unroll
       for (int mm = 0; mm < 4; mm++) sa[mm] = __builtin_amdgcn_mfma_f32_32x32x2f32(rg[slot][mm], qr[t], sa[mm], 0, 0, 0);
@@ -154,11 +166,11 @@ __global__ __launch_bounds__(256, RD <= 4 ? 3 : 2) void attn_rs_kernel(const flo
     issue(std::integral_constant<int, slot>(), std::integral_constant<int, (t + RD) % 64>());
     __builtin_amdgcn_sched_barrier(0);
   };
-#define ARS_STEPS8(B_, sn_)                                                                     \
-  step(std::integral_constant<int, B_ + 0>(), sn_); step(std::integral_constant<int, B_ + 1>(), sn_); \
-  step(std::integral_constant<int, B_ + 2>(), sn_); step(std::integral_constant<int, B_ + 3>(), sn_); \
-  step(std::integral_constant<int, B_ + 4>(), sn_); step(std::integral_constant<int, B_ + 5>(), sn_); \
-  step(std::integral_constant<int, B_ + 6>(), sn_); step(std::integral_constant<int, B_ + 7>(), sn_);
+#define ARS_STEPS8(B_, sn_)                                                                                           \
+  step(std::integral_constant<int, B_ + 0>(), sn_, ragged_c); step(std::integral_constant<int, B_ + 1>(), sn_, ragged_c); \
+  step(std::integral_constant<int, B_ + 2>(), sn_, ragged_c); step(std::integral_constant<int, B_ + 3>(), sn_, ragged_c); \
+  step(std::integral_constant<int, B_ + 4>(), sn_, ragged_c); step(std::integral_constant<int, B_ + 5>(), sn_, ragged_c); \
+  step(std::integral_constant<int, B_ + 6>(), sn_, ragged_c); step(std::integral_constant<int, B_ + 7>(), sn_, ragged_c);
   if (nst > 0 && active) {
     auto first = [&](auto t_c) { if constexpr (decltype(t_c)::value < RD) issue(t_c, t_c); };
     first(std::integral_constant<int, 0>()); first(std::integral_constant<int, 1>()); first(std::integral_constant<int, 2>()); first(std::integral_constant<int, 3>());

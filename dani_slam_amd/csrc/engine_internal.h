@@ -43,7 +43,6 @@ inline hipError_t stream_wait(hipStream_t s) {
   }
 }
 
-constexpr int CAND_CAP = 32768;  // candidates per frame kept on the device (reference reserves 10*nfeatures)
 constexpr int CAND_FAST = 4096;  // candidates per frame read back together with the counts (typical frames: 3-4 k)
 
 struct Context {
@@ -63,6 +62,7 @@ struct Context {
     std::vector<CellRect> cells;
     CellRect* d_cells = nullptr;
     int slot_stride = 0;
+    int cand_cap = 0;                 // candidates per frame = sum of the cell areas (every pixel of every cell): cannot overflow
     float* slot_xyr = nullptr;
     int32_t* slot_count = nullptr;
     float* cand = nullptr;

@@ -319,7 +319,10 @@ extern "C" {
 int dani_lg_set_kernel_option(const char* name, int32_t value) {
   if (!name) return DANI_ERR_INVALID;
   if (!strcmp(name, "lin_rs")) { if (value < -1 || value > 4) return DANI_ERR_INVALID; dani::g_lin_force_rs = value; return DANI_OK; }
-  if (!strcmp(name, "attn")) { if (value < 0 || value > 8) return DANI_ERR_INVALID; dani::g_attn_force = value; return DANI_OK; }
+  if (!strcmp(name, "attn")) {   // the documented kernels only: 1 / 3 / 4 / 5 (attn_ks, the bf16x3 forms on the f32 path, attn_k4 at any size) stay probe-only
+    if (value != 0 && value != 2 && value != 6 && value != 7 && value != 8) return DANI_ERR_INVALID;
+    dani::g_attn_force = value; return DANI_OK;
+  }
   return DANI_ERR_INVALID;
 }
 
@@ -419,7 +422,9 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
     HIP_TRY(e, hipMemcpyAsync(L->kpts, L->h_stage, (size_t)doff * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(e, hipMemcpyAsync(L->desc_tm, L->h_stage + (size_t)L->ld * 2, (size_t)doff * 1024, hipMemcpyHostToDevice, s));
   }
-  // padding columns of the tail region: keep the residual stream finite there (they are never read as keys)
+  // padding columns of the tail region: keep the residual stream finite there.  (They and the columns behind T CAN be read as
+  // key / value operands by attn_rs_kernel's ragged last super-tile, which loads whole 128-key tiles: their scores are masked
+  // and their V operands zeroed in the register -- attn_rs.h -- so nothing depends on what a previous, larger call left there.)
   if (T > T_main + ntail)
     HIP_TRY(e, hipMemset2DAsync(L->x + T_main + ntail, (size_t)L->ld * 4, 0, (size_t)(T - T_main - ntail) * 4, 256, s));
   memcpy(L->h_sets, L->last_sets.data(), sizeof(LgSet) * 2 * P);

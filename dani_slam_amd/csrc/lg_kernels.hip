@@ -1434,7 +1434,10 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
     // register-streaming form (attn_rs.h) unless DANI_ATTN_RS=0 or the probe asks for the LDS-tiled kernel (force 2)
     static const bool rs_off = getenv("DANI_ATTN_RS") && atoi(getenv("DANI_ATTN_RS")) == 0;
     static const int rs_tail_sign = getenv("DANI_ATTN_RS_TAIL_FIRST") ? -1 : 1;   // probe knob: tail-query workgroups first in dispatch order
-    if (force == 6 || (force == 0 && !rs_off))
+    // ... and unless every key set is shorter than one 128-key super-tile: a batch of many small sets (dani_lg_match_groups:
+    // ~200 sets of 40-60 keypoints) would run a whole super-tile -- 256 MFMAs, 64 16-byte loads -- per wave for 40-60 valid
+    // keys, 2-3x the work of attn_kernel<4>'s 32-key tiles
+    if (force == 6 || (force == 0 && !rs_off && max_mp >= 128))
       // ring of 8 loads, 2 waves per SIMD: equal to the ring of 4 at 3 waves per SIMD without tail queries, 2-3 us faster with
       // them (tools/probes/attn_bench.hip, profiles/r03_attn_rs_probe.txt; force 7 = the ring of 4)
       hipLaunchKernelGGL(attn_rs_kernel<8>, dim3((max_mp + 127) / 128 + max_tail, 4, nsets), dim3(256), 0, s, Q, K, V, O, ld, sets, rs_tail_sign * max_tail, cross, scale);

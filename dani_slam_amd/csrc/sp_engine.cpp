@@ -74,15 +74,22 @@ int ensure_shapes(dani_engine* e, Context* c, int W, int H, int B, int kcap, int
       max_area = std::max(max_area, cw * chh);
     }
     L.slot_stride = max_area;
+    // Candidate capacity = the sum of the cell areas: EVERY pixel of every cell (the 6-px overlap strips count twice, quirk Q5)
+    // can be a candidate, and the reference processes any count (vToDistributeKeys grows, src/SPextractor.cpp:248-312).  At
+    // 640x480 that is 204 cells x <= 1848 pixels = 4.4 MB per frame -- nothing against 288 GB -- so a dense frame (flat-high
+    // probability map) cannot overflow it; rounds 1-3 kept 32768 and answered DANI_ERR_CAPACITY beyond.
+    size_t area_sum = 0;
+    for (const CellRect& r : L.cells) area_sum += (size_t)(r.maxX - r.iniX) * (r.maxY - r.iniY);
+    L.cand_cap = (int)std::max<size_t>(area_sum, CAND_FAST);
     const int nc = std::max<int>(1, (int)L.cells.size());
     if ((rc = dev_alloc(e, c, (void**)&L.d_cells, sizeof(CellRect) * nc, false))) return rc;
     if (!L.cells.empty())
       HIP_TRY(e, hipMemcpyAsync(L.d_cells, L.cells.data(), sizeof(CellRect) * L.cells.size(), hipMemcpyHostToDevice, c->stream));
     if ((rc = dev_alloc(e, c, (void**)&L.slot_xyr, (size_t)B * nc * L.slot_stride * 3 * 4, false))) return rc;
     if ((rc = dev_alloc(e, c, (void**)&L.slot_count, (size_t)B * nc * 4, true))) return rc;
-    if ((rc = dev_alloc(e, c, (void**)&L.cand, (size_t)B * CAND_CAP * 3 * 4, false))) return rc;
+    if ((rc = dev_alloc(e, c, (void**)&L.cand, (size_t)B * L.cand_cap * 3 * 4, false))) return rc;
     if ((rc = dev_alloc(e, c, (void**)&L.cand_count, (size_t)B * 4, true))) return rc;
-    if ((rc = host_alloc(e, c, (void**)&L.h_cand, (size_t)B * CAND_CAP * 3 * 4))) return rc;
+    if ((rc = host_alloc(e, c, (void**)&L.h_cand, (size_t)B * L.cand_cap * 3 * 4))) return rc;
     if ((rc = host_alloc(e, c, (void**)&L.h_cand_count, (size_t)B * 4))) return rc;
     if (l > 0 && (rc = dev_alloc(e, c, (void**)&L.d_level_img, (size_t)B * h * w, false))) return rc;
   }
@@ -252,9 +259,9 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       if (ncells > 0) {
         launch_cell_nms(L.prob, PH, PW, B, L.d_cells, ncells, p->ini_th, p->min_th, d_boxes, d_box_offsets,
                         19 - 3, scales[l], L.slot_xyr, L.slot_count, L.slot_stride, s);
-        launch_cell_compact(L.slot_xyr, L.slot_count, ncells, L.slot_stride, B, L.cand, L.cand_count, CAND_CAP, s);
+        launch_cell_compact(L.slot_xyr, L.slot_count, ncells, L.slot_stride, B, L.cand, L.cand_count, L.cand_cap, s);
         HIP_TRY(e, hipMemcpyAsync(L.h_cand_count, L.cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipMemcpy2DAsync(L.h_cand, (size_t)CAND_CAP * 12, L.cand, (size_t)CAND_CAP * 12, (size_t)CAND_FAST * 12, B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpy2DAsync(L.h_cand, (size_t)L.cand_cap * 12, L.cand, (size_t)L.cand_cap * 12, (size_t)CAND_FAST * 12, B, hipMemcpyDeviceToHost, s));
       }
     }
     return 0;
@@ -338,11 +345,12 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       Context::Level& L = c->lv[l];
       for (int b = 0; b < B; b++) {
         int nc = L.cells.empty() ? 0 : L.h_cand_count[b];
-        if (nc > CAND_CAP) return fail(e, DANI_ERR_CAPACITY, "frame %d level %d has %d candidates (> %d)", b, l, nc, CAND_CAP);
+        if (nc < 0 || nc > L.cand_cap)   // more candidates than cell pixels: memory corruption, not a capacity case
+          return fail(e, DANI_ERR_HIP, "frame %d level %d: candidate counter %d outside [0, %d]", b, l, nc, L.cand_cap);
         L.h_cand_count[b] = nc;
         if (nc > CAND_FAST) {
           more = true;
-          HIP_TRY(e, hipMemcpyAsync(L.h_cand + ((size_t)b * CAND_CAP + CAND_FAST) * 3, L.cand + ((size_t)b * CAND_CAP + CAND_FAST) * 3, (size_t)(nc - CAND_FAST) * 12, hipMemcpyDeviceToHost, s));
+          HIP_TRY(e, hipMemcpyAsync(L.h_cand + ((size_t)b * L.cand_cap + CAND_FAST) * 3, L.cand + ((size_t)b * L.cand_cap + CAND_FAST) * 3, (size_t)(nc - CAND_FAST) * 12, hipMemcpyDeviceToHost, s));
         }
       }
     }
@@ -361,7 +369,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     std::vector<char> okf(B, 1);
     host_pool().run(B, [&](int b) {
       const Context::Level& L = c->lv[0];
-      const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+      const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * L.cand_cap * 3);
       okf[b] = distribute_octtree(keys, L.h_cand_count[b], minBorderX, L.W - 19 + 3, minBorderY, L.H - 19 + 3, per_level[0], c->spec_sels[b]);
     });
     bool all_ok = true;
@@ -397,7 +405,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     std::vector<std::vector<int>> sels(NL);
     for (int l = 0; l < NL; l++) {
       const Context::Level& L = c->lv[l];
-      HostKey* keys = reinterpret_cast<HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+      HostKey* keys = reinterpret_cast<HostKey*>(L.h_cand + (size_t)b * L.cand_cap * 3);
       bool culled = false;
       if (host_cull && boxes && box_offsets && box_offsets[b + 1] > box_offsets[b]) {
         // dynamic-box cull of SPextractor.cpp:314-352 at scale 1: (p + border) tested with Rect::contains (left / top
@@ -435,7 +443,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     const int l0 = lapping ? lapping[0] : 0, l1 = lapping ? lapping[1] : 0;
     for (int l = 0; l < NL; l++) {
       const Context::Level& L = c->lv[l];
-      const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * CAND_CAP * 3);
+      const HostKey* keys = reinterpret_cast<const HostKey*>(L.h_cand + (size_t)b * L.cand_cap * 3);
       const std::vector<int>& sel = sels[l];
       const int nl = fits ? (int)sel.size() : 0;
       h_lv[(l * 2 + 0) * MB + b] = off;
@@ -531,7 +539,7 @@ int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* desc_map,
   if (n_cand) *n_cand = L.h_cand_count[b];
   if (cand_xyr) {
     const int n = std::min(L.h_cand_count[b], cand_cap);
-    memcpy(cand_xyr, L.h_cand + (size_t)b * CAND_CAP * 3, (size_t)n * 12);
+    memcpy(cand_xyr, L.h_cand + (size_t)b * L.cand_cap * 3, (size_t)n * 12);
   }
   return DANI_OK;
 }

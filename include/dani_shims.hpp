@@ -94,7 +94,11 @@ class SPextractor {
       // A run-time engine error on one frame must not end the SLAM process (the reference exits only when the MODEL
       // cannot be loaded, src/SPextractor.cpp:88-91): report it and hand back what operator() returns for a frame it
       // cannot process (-1, no keypoints, :133-134); Frame's constructors return early on an empty keypoint set.
-      std::cerr << "[SPextractor] " << dani_last_error(dani_shim::engine()) << std::endl;
+      // Every such frame is logged and counted (mnDroppedFrames / DroppedFrames()); since round 4 a dense frame is not
+      // among them: the candidate buffers hold every pixel of every cell (csrc/sp_engine.cpp).
+      ++mnDroppedFrames;
+      std::cerr << "[SPextractor] frame dropped (" << mnDroppedFrames << " so far, status " << rc << "): "
+                << dani_last_error(dani_shim::engine()) << std::endl;
       _keypoints.clear(); _descriptors.release();
       return -1;
     }
@@ -117,6 +121,8 @@ class SPextractor {
   std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
   int mLastStatus = DANI_OK;                 // dani_status of the last operator() call (not in the reference)
+  long mnDroppedFrames = 0;                  // frames this extractor handed back empty because the engine reported an error
+  long DroppedFrames() const { return mnDroppedFrames; }
   std::vector<cv::Mat> mvImagePyramid;       // kept for source compatibility (not filled: the pyramid lives in HBM)
   std::vector<cv::Rect2i> mvDynamicArea;     // written by Tracking::GrabImageRGBD, src/Tracking.cc:1539
 

@@ -60,6 +60,11 @@ int main(int argc, char** argv) {
   const int mono8 = ex8(m0, cv::Mat(), k8, d8, lap);
   put_i(ex8.mLastStatus); put_i(mono8); put_i((int)k8.size()); put_i(d8.rows);
   for (auto& k : k8) { put_f(&k.pt.x, 1); put_f(&k.pt.y, 1); put_i(k.octave); }
+  // a frame the engine refuses (64 x 48: below its 80 x 80 minimum): handed back empty like an empty image, logged and counted
+  cv::Mat tiny(48, 64, CV_8UC1, g0.data());
+  std::vector<cv::KeyPoint> kt; cv::Mat dt;
+  put_i((int)ex.DroppedFrames());
+  put_i(ex(tiny, cv::Mat(), kt, dt, lap)); put_i(ex.mLastStatus); put_i((int)ex.DroppedFrames()); put_i((int)kt.size());
   fclose(out);
   printf("shim_smoke ok: %zu + %zu keypoints, %zu matches, %zu dynamic boxes\n", k0.size(), k1.size(), matches.size(), det.mvDynamicArea.size());
   return 0;

@@ -317,3 +317,33 @@ def test_register_streaming_kernels_match_the_lds_tiled_ones(lg_weights, sp_weig
             e.lg_set_kernel_option(k, v)
         e.close()
 
+
+
+def test_non_finite_inputs_do_not_poison_later_calls(lg_weights, sp_weights):
+    """A call whose descriptors hold NaN leaves NaN in its workspace columns.  A later, SMALLER batch ends in front of those
+    columns, and the register-streaming attention loads whole 128-key super-tiles: the ragged last tile of the last set reads
+    up to 127 columns past the set (masked scores, V operands multiplied by P = 0 -- 0 * NaN unless they are zeroed in the
+    register, attn_rs.h).  The smaller batch must give bit for bit what it gave before the NaN call."""
+    from dani_slam_amd import frontend
+    w = dict(sp_weights); w.update(lg_weights)
+    e = frontend.Engine(device=0, weights=w, max_batch=8)
+
+    def batch(sz, seed):
+        prs = [synth.matching_pair(seed + i, n0=a, n1=b) for i, (a, b) in enumerate(sz)]
+        cap = max(max(a, b) for a, b in sz) + 2
+        K0 = np.zeros((len(sz), cap, 2), np.float32); D0 = np.zeros((len(sz), cap, 256), np.float32)
+        K1 = np.zeros((len(sz), cap, 2), np.float32); D1 = np.zeros((len(sz), cap, 256), np.float32)
+        for p, (k0, d0, k1, d1, _) in enumerate(prs):
+            K0[p, :len(k0)] = k0; D0[p, :len(k0)] = d0; K1[p, :len(k1)] = k1; D1[p, :len(k1)] = d1
+        return [K0, D0, [a for a, _ in sz], K1, D1, [b for _, b in sz]]
+    small = batch([(1030, 1030)] * 6 + [(1030, 1000)], 190)         # key sets whose last super-tile holds 6 / 104 valid keys
+    big = batch([(1200, 1200)] * 8, 40)
+    before = e.lg_match_batch(*small, SIZE, SIZE, 0.05)
+    assert min(len(m) for m, _ in before) > 300
+    big[1][:] = np.nan; big[4][:] = np.nan                           # every descriptor of the big batch
+    poisoned = e.lg_match_batch(*big, SIZE, SIZE, 0.05)
+    assert all(len(m) == 0 for m, _ in poisoned)                     # NaN scores never pass the threshold
+    after = e.lg_match_batch(*small, SIZE, SIZE, 0.05)
+    for (m0, s0), (m1, s1) in zip(before, after):
+        assert np.array_equal(m0, m1) and np.array_equal(s0, s1)
+    e.close()

@@ -70,7 +70,11 @@ def test_cpp_shims_match_ctypes_path(tmp_path, sp_weights):
     for _ in range(n8):
         x, y = getf(2)
         k8.append((x, y, geti()))
+    dropped_before, tiny_rc, tiny_status, dropped_after, tiny_n = geti(), geti(), geti(), geti(), geti()
     assert pos == len(buf) and ok == 1 and empty_rc == -1
+    # an engine error on one frame: -1 and no keypoints (as for an empty image), counted, never silent
+    assert (dropped_before, tiny_rc, tiny_status, dropped_after, tiny_n) == (0, -1, frontend.DANI_ERR_UNSUPPORTED, 1, 0)
+    assert "frame dropped (1 so far" in out.stderr
 
     # the same calls through the ctypes mirror
     e = frontend.Engine(device=0, max_batch=8, max_width=1280, max_height=1024, weights=w)

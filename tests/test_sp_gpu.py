@@ -94,6 +94,29 @@ def test_other_params_and_thresholds(engine, sp_weights, oracle_frames):
         assert np.array_equal(r["desc"], ref["desc"])
 
 
+def test_dense_frames_have_no_candidate_limit(engine, sp_weights):
+    """A frame on which EVERY pixel of every cell is a candidate (thresholds 0: prob > 0 holds everywhere) -- 204 cells x up
+    to 1848 pixels, the 6-px overlap strips counted twice (quirk Q5): ~350 k candidates where rounds 1-3 answered
+    DANI_ERR_CAPACITY above 32 768.  The reference processes any count (vToDistributeKeys grows,
+    /root/reference/src/SPextractor.cpp:248-312); so does the engine, with boxes and in a batch next to a sparse frame."""
+    img = synth.frame(1)
+    ref = oracle.sp_extract(img, sp_weights, nfeatures=1024, iniTh=0.0, minTh=0.0)
+    r = engine.sp_extract_batch(img[None], nfeatures=1024, iniTh=0.0, minTh=0.0)[0]
+    _, _, cand = engine.sp_debug_fetch(0, 480, 640, cand_cap=1 << 19)
+    from dani_slam_amd import frontend
+    cells = frontend.host_cell_grid(640, 480)      # (iniX, maxX, iniY, maxY, offX, offY) of the non-skipped cells
+    assert len(cand) == int(((cells[:, 1] - cells[:, 0]) * (cells[:, 3] - cells[:, 2])).sum()) > 300_000      # every cell pixel
+    assert np.array_equal(r["kpts"], ref["kpts"]) and np.array_equal(r["resp"], ref["resp"])
+    assert np.array_equal(r["desc"], ref["desc"])
+    boxes = [(100, 60, 300, 200), (500, 300, 90, 120)]
+    refb = oracle.sp_extract(img, sp_weights, nfeatures=2000, iniTh=0.0, minTh=0.0, boxes=boxes)
+    two = engine.sp_extract_batch(np.stack([img, synth.frame(2)]), nfeatures=2000, iniTh=0.0, minTh=0.0,
+                                  boxes=[np.array(boxes, np.int32), np.zeros((0, 4), np.int32)])
+    assert np.array_equal(two[0]["kpts"], refb["kpts"]) and np.array_equal(two[0]["desc"], refb["desc"])
+    ref2 = oracle.sp_extract(synth.frame(2), sp_weights, nfeatures=2000, iniTh=0.0, minTh=0.0)
+    assert np.array_equal(two[1]["kpts"], ref2["kpts"]) and np.array_equal(two[1]["desc"], ref2["desc"])
+
+
 def test_non_contiguous_stride_and_smaller_image(sp_weights):
     from dani_slam_amd import frontend
     e = frontend.Engine(device=0, max_batch=1, max_width=640, max_height=480, weights=sp_weights)
