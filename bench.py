@@ -165,6 +165,10 @@ def main():
     ap.add_argument("--force-boundary-exchange", action="store_true",
                     help="N = 1 only: take the N > 1 code path (extract, export of the last frame's features on the device, "
                          "match against the carried slab) to price the split call on one GPU")
+    ap.add_argument("--exchange", choices=("native", "torch"), default="native",
+                    help="N > 1: who runs the shard-boundary all-gather -- native = the engine itself (ncclAllGather behind the C ABI on the "
+                         "sequence's stream, csrc/comm_engine.cpp; default with the nccl backend), torch = torch.distributed's "
+                         "all_gather_into_tensor (the form of rounds 2-3; always used by the gloo rehearsal on one device)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra bf16x3 / batch-1 measurements (profiling runs)")
     ap.add_argument("--host-wait", choices=("spin", "block"), default="block",
                     help="how the calling thread waits for the GPU inside the engine (dani_set_host_wait): block = the library's default "
@@ -225,6 +229,26 @@ def main():
     pipelined = boundary and not args.no_pipelined_exchange
     pend = {"job": None, "step": 0}
     xchg = None
+    # the collective itself: native RCCL inside the engine when every rank owns a GPU (RCCL refuses two ranks on one device: the
+    # gloo / one-device rehearsal keeps torch.distributed's form).  A communicator that cannot be built is reported and replaced
+    # by the torch form -- the line's `parallelism` field says which one ran.
+    native = None
+    exchange_used = "none"
+    if boundary:
+        exchange_used = "torch.distributed all_gather_into_tensor"
+        if args.exchange == "native" and (backend == "nccl" or world == 1) and os.environ.get("DANI_BENCH_ONE_DEVICE") != "1":
+            try:
+                native = sharding.NativeExchange(eng, CAP, rank, world)
+                exchange_used = f"native ncclAllGather behind the C ABI (RCCL {native.info()['rccl_version']}, dani_frontend_exchange_boundary)"
+            except Exception as ex:
+                print(f"[bench rank {rank}] native RCCL exchange unavailable ({ex}); using torch.distributed", file=sys.stderr, flush=True)
+                native = None
+        if world > 1:      # all ranks must agree (a rank that failed alone would leave the others waiting in the collective)
+            flag = torch.tensor([1 if native is not None else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and native is not None:
+                native.close(); native = None
+                exchange_used = "torch.distributed all_gather_into_tensor (native RCCL failed on another rank)"
 
     def call(mode, seq=0, nb=None):
         """mode 4: full front-end; 2: SuperPoint extract only; 3: SuperPoint x 2 + LightGlue of the (left, right) pair."""
@@ -242,7 +266,11 @@ def main():
             out_ = eng.frontend_batch(frames[:nb], frames_bgr[:nb] if mode == 4 else None, **kw)
         else:
             out_ = eng.frontend_batch(None, None, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()), shape=(nb, H, W), **kw)
-        if mode == 4 and boundary:
+        if mode == 4 and boundary and native is not None:
+            native.start(nb - 1, seq)                       # pack + ncclAllGather on the sequence's stream, no host wait
+            for o_, (m_, s_) in zip(out_, native.match(nb, seq)):
+                o_["matches"], o_["scores"] = m_, s_
+        elif mode == 4 and boundary:
             match_boundary(out_, sharding.exchange_boundary_features(eng, nb - 1, CAP, reduce_dev, seq), nb, seq)
         return out_
 
@@ -267,11 +295,15 @@ def main():
             return None
         pend["job"] = None
         out_, ticket, nb_, seq_ = job
+        if native is not None:
+            for o_, (m_, s_) in zip(out_, native.match(nb_, seq_)):
+                o_["matches"], o_["scores"] = m_, s_
+            return out_
         return match_boundary(out_, xchg.wait(ticket), nb_, seq_)
 
     def call_pipelined(kw, nb):
         nonlocal xchg
-        if xchg is None:
+        if xchg is None and native is None:
             xchg = sharding.BoundaryExchange(eng, CAP, reduce_dev)
         seq = pend["step"] & 1
         pend["step"] += 1
@@ -282,7 +314,7 @@ def main():
             out_ = eng.frontend_batch(None, None, device_ptrs=(d_frames.data_ptr(), d_bgr.data_ptr()), shape=(nb, H, W), **kw)
         if pend.get("sample"):                    # SuperPoint's layer timers belong to THIS extraction's context: read them now
             pend["lt"], pend["ft"] = eng.layer_timings(), eng.frontend_timings()
-        ticket = xchg.start(nb - 1, seq)
+        ticket = native.start(nb - 1, seq) if native is not None else xchg.start(nb - 1, seq)
         done = finish_pending()                  # LightGlue of the PREVIOUS step, whose all-gather was posted one extraction ago
         pend["job"] = (out_, ticket, nb, seq)
         return done if done is not None else out_
@@ -480,6 +512,7 @@ def main():
                              "first_frame_matches_per_rank": first_pair,
                              "note_matches": "frame 0 of a step is matched against frame B-1 of the previous step (the same 8 frames "
                                              "are replayed every step): a 14-degree jump, few matches; frames 1..B-1 are consecutive",
+                             "exchange": exchange_used,
                              "parallelism": (f"frame-sharded x{world}; one all-gather of every rank's last-frame features per step (1 MB per rank, "
                                              "device buffers) for the pair that crosses a shard boundary"
                                              + ("; posted after a step's extraction and waited for one extraction later: the LightGlue of "

@@ -174,6 +174,7 @@ void dani_engine_destroy(dani_engine* e) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   }
+  comm_release(e);   // after the stream synchronises above: no collective is in flight
   lg_release(e); yolo_release(e); seq_release(e);
   for (Context* c : e->ctxs) {
     free_buffers(c);

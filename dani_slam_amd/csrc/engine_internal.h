@@ -109,7 +109,23 @@ struct Context {
 
 struct LgWeights;
 struct YoloWeights;
-struct SeqState;
+struct CommState;   // comm_engine.cpp: the RCCL communicator of a sharded batch
+// one image sequence (camera) of dani_frontend_batch: own context (stream, workspaces, cached predecessor frame)
+struct SeqState {
+  std::mutex mu;
+  Context* ctx = nullptr;
+  std::vector<std::string> class_names, dynamic_names;
+  float ms[4] = {0, 0, 0, 0};
+  // per-call host scratch, kept between calls (a fresh 0.8 MB vector per call costs a memset on the critical path)
+  std::vector<float> dets, size;
+  std::vector<int32_t> octave, frame_boxes;
+  // resident features of the last dani_frontend_batch call (for dani_frontend_export_features / _match_resident)
+  int res_B = 0, res_W = 0, res_H = 0;
+  std::vector<int32_t> res_n;
+  // descriptor read-back left running by a defer_desc call: stream2 is filling the pinned staging, `pend_desc` is the caller's array
+  float* pend_desc = nullptr;
+  int pend_cap = 0;
+};
 
 
 }  // namespace eng
@@ -134,6 +150,7 @@ struct dani_engine {
   dani::eng::LgWeights* lgw = nullptr;             // packed LightGlue / YOLO weights (owned; device buffers are in weight_allocs)
   dani::eng::YoloWeights* yw = nullptr;
   std::map<int, dani::eng::SeqState*> seqs;        // dani_frontend_batch sequences (own context + cached previous frame), under mu
+  dani::eng::CommState* comm = nullptr;            // dani_comm_create: RCCL communicator + gather buffers (owned)
 };
 
 
@@ -308,6 +325,17 @@ int yolo_finalize(dani_engine* e);
 void lg_release(dani_engine* e);     // workspaces and packed weights die with the engine
 void yolo_release(dani_engine* e);
 void seq_release(dani_engine* e);
+void comm_release(dani_engine* e);   // comm_engine.cpp
+SeqState* seq_state(dani_engine* e, int id = 0);   // frontend_engine.cpp
+void finish_pending_desc(SeqState* S);
+int match_resident_locked(dani_engine* e, SeqState* S, int32_t sequence, const float* pred, int32_t pred_on_device, int32_t pred_cap,
+                          float lg_threshold, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out);
+extern thread_local SeqState* t_last_seq;
+}  // namespace eng
+void launch_pack_features(const float* kimg, const float* desc, int n, int cap, float* dst, hipStream_t s);   // handoff_kernels.hip
+namespace eng {
+// device-side packing of one frame's features into the slab layout of dani_frontend_export_features (handoff_kernels.hip):
+// dst[0] = n, kpts [cap][2], desc [cap][256]; the unused tail of both arrays is zero-filled
 
 }  // namespace eng
 }  // namespace dani

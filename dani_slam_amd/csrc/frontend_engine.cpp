@@ -12,21 +12,6 @@ using namespace dani::eng;
 namespace dani {
 namespace eng {
 
-struct SeqState {
-  std::mutex mu;
-  Context* ctx = nullptr;
-  std::vector<std::string> class_names, dynamic_names;
-  float ms[4] = {0, 0, 0, 0};
-  // per-call host scratch, kept between calls (a fresh 0.8 MB vector per call costs a memset on the critical path)
-  std::vector<float> dets, size;
-  std::vector<int32_t> octave, frame_boxes;
-  // resident features of the last dani_frontend_batch call (for dani_frontend_export_features / _match_resident)
-  int res_B = 0, res_W = 0, res_H = 0;
-  std::vector<int32_t> res_n;
-  // descriptor read-back left running by a defer_desc call: stream2 is filling the pinned staging, `pend_desc` is the caller's array
-  float* pend_desc = nullptr;
-  int pend_cap = 0;
-};
 // finish a deferred descriptor read-back (wait for the staging copy, move it into the caller's array); S->mu is held
 void finish_pending_desc(SeqState* S) {
   if (!S->pend_desc || !S->ctx) { S->pend_desc = nullptr; return; }
@@ -39,7 +24,7 @@ void finish_pending_desc(SeqState* S) {
   });
 }
 // one SeqState (context + cached previous frame) per (engine, sequence id); id 0 also holds the class lists
-SeqState* seq_state(dani_engine* e, int id = 0) {
+SeqState* seq_state(dani_engine* e, int id) {
   std::lock_guard<std::mutex> lk(e->mu);
   auto it = e->seqs.find(id);
   if (it != e->seqs.end()) return it->second;
@@ -55,6 +40,57 @@ void seq_release(dani_engine* e) {
   // never copied -- the caller's array may be gone by now (include/dani_frontend.h, dani_frontend_finish_pending)
   for (auto& kv : e->seqs) { if (t_last_seq == kv.second) t_last_seq = nullptr; kv.second->pend_desc = nullptr; delete kv.second; }
   e->seqs.clear();
+}
+
+}  // namespace eng
+}  // namespace dani
+
+
+namespace dani {
+namespace eng {
+
+// dani_frontend_match_resident with S->mu held (also the tail of dani_frontend_match_exchanged, comm_engine.cpp)
+int match_resident_locked(dani_engine* e, SeqState* S, int32_t sequence, const float* pred, int32_t pred_on_device, int32_t pred_cap,
+                          float lg_threshold, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out) {
+  Context* c = S->ctx;
+  const int B = S->res_B;
+  if (!c || B < 1) return fail(e, DANI_ERR_INVALID, "sequence %d holds no resident frames (call dani_frontend_batch first)", sequence);
+  HIP_TRY(e, hipSetDevice(e->device));
+  t_last_seq = S;
+  if (pred) {   // the neighbouring rank's last frame becomes slot 0 of the feature slabs
+    float cnt = 0.0f;
+    if (pred_on_device) {
+      // ordered on the sequence's own stream: a slab that a collective enqueued on this stream is still writing
+      // (dani_frontend_exchange_boundary) is complete when the count arrives; a null-stream hipMemcpy would not wait for it
+      HIP_TRY(e, hipMemcpyAsync(c->h_boxes, pred, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(e, hipStreamSynchronize(c->stream));
+      memcpy(&cnt, c->h_boxes, 4);
+    } else cnt = pred[0];
+    const int pn = (int)cnt;
+    if (!(cnt >= 0.0f) || pn < 0 || pn > pred_cap || pn > c->kcap) return fail(e, DANI_ERR_INVALID, "predecessor slab holds %d keypoints (cap %d, engine %d)", pn, pred_cap, c->kcap);
+    const hipMemcpyKind kind = pred_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (pn) {
+      HIP_TRY(e, hipMemcpyAsync(c->d_kimg_all, pred + 1, (size_t)pn * 8, kind, c->stream));
+      HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, pred + 1 + (size_t)pred_cap * 2, (size_t)pn * 1024, kind, c->stream));
+    }
+    c->prev_n = pn;
+  }
+  std::vector<int32_t> n0(B), n1(B);
+  for (int b = 0; b < B; b++) { n0[b] = b ? S->res_n[b - 1] : c->prev_n; n1[b] = S->res_n[b]; }
+  const float sz[2] = {(float)S->res_W, (float)S->res_H};
+  LgCall lg_call;
+  lg_call.ctx = c;
+  std::function<void()> finish_desc = [&] { finish_pending_desc(S); };   // a deferred descriptor read-back ends under the forward pass
+  lg_call.overlap = &finish_desc;
+  int rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kimg_all, c->d_desc_all, n0.data(), c->d_kimg, c->d_descout, n1.data(), sz, sz,
+                         lg_threshold, matches, scores, match_cap, k_out);
+  finish_pending_desc(S);
+  if (rc) return rc;
+  HIP_TRY(e, hipMemcpyAsync(c->d_kimg_all, c->d_kimg + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
+  // no host wait: every later use of the cache slabs is enqueued on this same stream
+  c->prev_n = S->res_n[B - 1];
+  return DANI_OK;
 }
 
 }  // namespace eng
@@ -317,39 +353,7 @@ int dani_frontend_match_resident(dani_engine* e, int32_t sequence, const float* 
   if (!matches || !scores || !k_out || match_cap < 1 || (pred && pred_cap < 1)) return fail(e, DANI_ERR_INVALID, "bad dani_frontend_match_resident argument");
   SeqState* S = seq_state(e, sequence);
   std::lock_guard<std::mutex> seq_lock(S->mu);
-  Context* c = S->ctx;
-  const int B = S->res_B;
-  if (!c || B < 1) return fail(e, DANI_ERR_INVALID, "sequence %d holds no resident frames (call dani_frontend_batch first)", sequence);
-  HIP_TRY(e, hipSetDevice(e->device));
-  t_last_seq = S;
-  if (pred) {   // the neighbouring rank's last frame becomes slot 0 of the feature slabs
-    float cnt = 0.0f;
-    HIP_TRY(e, hipMemcpy(&cnt, pred, 4, pred_on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
-    const int pn = (int)cnt;
-    if (pn < 0 || pn > pred_cap || pn > c->kcap) return fail(e, DANI_ERR_INVALID, "predecessor slab holds %d keypoints (cap %d, engine %d)", pn, pred_cap, c->kcap);
-    const hipMemcpyKind kind = pred_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (pn) {
-      HIP_TRY(e, hipMemcpyAsync(c->d_kimg_all, pred + 1, (size_t)pn * 8, kind, c->stream));
-      HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, pred + 1 + (size_t)pred_cap * 2, (size_t)pn * 1024, kind, c->stream));
-    }
-    c->prev_n = pn;
-  }
-  std::vector<int32_t> n0(B), n1(B);
-  for (int b = 0; b < B; b++) { n0[b] = b ? S->res_n[b - 1] : c->prev_n; n1[b] = S->res_n[b]; }
-  const float sz[2] = {(float)S->res_W, (float)S->res_H};
-  LgCall lg_call;
-  lg_call.ctx = c;
-  std::function<void()> finish_desc = [&] { finish_pending_desc(S); };   // a deferred descriptor read-back ends under the forward pass
-  lg_call.overlap = &finish_desc;
-  int rc = lg_match_impl(e, lg_call, B, c->kcap, 1, c->d_kimg_all, c->d_desc_all, n0.data(), c->d_kimg, c->d_descout, n1.data(), sz, sz,
-                         lg_threshold, matches, scores, match_cap, k_out);
-  finish_pending_desc(S);
-  if (rc) return rc;
-  HIP_TRY(e, hipMemcpyAsync(c->d_kimg_all, c->d_kimg + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream));
-  HIP_TRY(e, hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream));
-  // no host wait: every later use of the cache slabs is enqueued on this same stream
-  c->prev_n = S->res_n[B - 1];
-  return DANI_OK;
+  return match_resident_locked(e, S, sequence, pred, pred_on_device, pred_cap, lg_threshold, matches, scores, match_cap, k_out);
 }
 
 }  // extern "C"

@@ -167,4 +167,25 @@ void launch_area_fill(const float* kxy, const int32_t* octave, float min_x, floa
                      cell_idx, qx, qy, qr, min_level, max_level, nq, nullptr, cand_offsets, cand_idx);
 }
 
+// ---------------------------------------------------------------------------------------------
+// One frame's features packed into the slab the shard-boundary all-gather moves (comm_engine.cpp; layout of
+// dani_frontend_export_features): dst[0] = n, kpts [cap][2] at dst + 1, desc [cap][256] at dst + 1 + 2 cap; rows >= n are
+// zero-filled so that the gathered bytes are fully defined.  1.06 MB at cap = 1036: HBM-bound copy, ~2 us.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_features_kernel(const float* kimg, const float* desc, int n, int cap, float* dst) {
+  const size_t total = (size_t)cap * 258;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) dst[0] = (float)n;
+  if (i >= total) return;
+  const size_t nk = (size_t)cap * 2;
+  float v;
+  if (i < nk) v = i < (size_t)n * 2 ? kimg[i] : 0.0f;
+  else { const size_t j = i - nk; v = j < (size_t)n * 256 ? desc[j] : 0.0f; }
+  dst[1 + i] = v;
+}
+void launch_pack_features(const float* kimg, const float* desc, int n, int cap, float* dst, hipStream_t s) {
+  const size_t total = (size_t)cap * 258;
+  hipLaunchKernelGGL(pack_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kimg, desc, n, cap, dst);
+}
+
 }  // namespace dani

@@ -123,6 +123,13 @@ def load_library():
     lib.dani_frontend_export_features.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, _i32]
     lib.dani_frontend_match_resident.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_timings.argtypes = [C.c_void_p, _f]
+    lib.dani_comm_unique_id.argtypes = [C.c_void_p, C.c_int32]
+    lib.dani_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.dani_comm_destroy.argtypes = [C.c_void_p]
+    lib.dani_comm_reset_carry.argtypes = [C.c_void_p]
+    lib.dani_comm_info.argtypes = [C.c_void_p, _i32, _i32, _i32, C.POINTER(C.c_int64)]
+    lib.dani_frontend_exchange_boundary.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), _i32]
+    lib.dani_frontend_match_exchanged.argtypes = [C.c_void_p, C.c_int32, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_desc_best2.argtypes = [C.c_void_p, _f, C.c_int32, _f, C.c_int32, _i32, _i32, _i32, _f, _f, _i32, _i32, _i32]
     lib.dani_host_distribute_octtree.argtypes = [_f, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                  C.c_int32, _i32, C.c_int32]
@@ -562,6 +569,53 @@ class Engine:
         else:
             pp, on_dev, pred_cap = None, 0, 0
         self._check(self.lib.dani_frontend_match_resident(self.h, sequence, pp, on_dev, pred_cap, C.c_float(lg_threshold), _ip(m), _fp(sc), cap, _ip(k)))
+        return [(m[b, :k[b]].copy(), sc[b, :k[b]].copy()) for b in range(nframes)]
+
+    # -- the sharded batch's collective, native (RCCL all-gather behind the C ABI; include/dani_frontend.h) -------------
+    COMM_ID_BYTES = 128
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId through the engine's library (rank 0); hand the 128 bytes to the other ranks by any means."""
+        lib = load_library()
+        buf = C.create_string_buffer(Engine.COMM_ID_BYTES)
+        rc = lib.dani_comm_unique_id(buf, Engine.COMM_ID_BYTES)
+        if rc:
+            raise DaniError(rc, lib.dani_last_error(None).decode())
+        return buf.raw
+
+    def comm_create(self, unique_id: bytes, rank: int, world: int):
+        """ncclCommInitRank on the engine's GPU: a collective, every rank calls it with the same id."""
+        assert len(unique_id) >= self.COMM_ID_BYTES
+        buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
+        self._check(self.lib.dani_comm_create(self.h, buf, len(unique_id), rank, world))
+
+    def comm_destroy(self):
+        self._check(self.lib.dani_comm_destroy(self.h))
+
+    def comm_reset_carry(self):
+        self._check(self.lib.dani_comm_reset_carry(self.h))
+
+    def comm_info(self):
+        """dict(rank, world, rccl_version, collectives) of the engine's communicator."""
+        r = C.c_int32(0); w = C.c_int32(0); v = C.c_int32(0); n = C.c_int64(0)
+        self._check(self.lib.dani_comm_info(self.h, C.byref(r), C.byref(w), C.byref(v), C.byref(n)))
+        return dict(rank=r.value, world=w.value, rccl_version=v.value, collectives=n.value)
+
+    def frontend_exchange_boundary(self, frame, cap, sequence=0, device_ptr=None):
+        """Pack resident frame `frame` and all-gather it over the communicator (enqueued on the sequence's stream, no host
+        wait).  Returns (keypoint count of the own frame, device address of the gathered [world][1 + cap * 258] floats)."""
+        n = C.c_int32(0); out = C.c_void_p()
+        self._check(self.lib.dani_frontend_exchange_boundary(self.h, sequence, frame, cap, C.c_void_p(device_ptr) if device_ptr else None,
+                                                             C.byref(out), C.byref(n)))
+        return n.value, out.value
+
+    def frontend_match_exchanged(self, nframes, cap=None, lg_threshold=0.05, sequence=0):
+        """LightGlue over the resident frames, frame 0 against the neighbouring rank's slab of the sequence's last exchange
+        (rank 0: the last rank's slab of the previous exchange).  Returns a list of (matches [k,2], scores [k]) per frame."""
+        cap = cap or 4096
+        m = np.zeros((nframes, cap, 2), np.int32); sc = np.zeros((nframes, cap), np.float32); k = np.zeros(nframes, np.int32)
+        self._check(self.lib.dani_frontend_match_exchanged(self.h, sequence, C.c_float(lg_threshold), _ip(m), _fp(sc), cap, _ip(k)))
         return [(m[b, :k[b]].copy(), sc[b, :k[b]].copy()) for b in range(nframes)]
 
     def frontend_timings(self):

@@ -1,9 +1,15 @@
 """Multi-GPU plumbing for the front-end: frames are independent units, so ranks take
 disjoint frame blocks with NO data-path collective.  The only exchange the design foresees is one all-gather of
-per-frame features (count, keypoints, responses, descriptors) for the multi-camera / batched-sequence LightGlue
-case, where a pair's two frames live on different GPUs.  `torch.distributed` is plumbing here: backend "nccl" is
-RCCL over xGMI on the MI355X node, "gloo" is used by the CPU tests.  ~1.06 MB per 1024-keypoint frame: one direct
-all-gather per batch (all 7 xGMI links of a GPU in parallel), not a ring of small messages.
+per-frame features (count, keypoints, descriptors) for the multi-camera / batched-sequence LightGlue case, where a
+pair's two frames live on different GPUs.  ~1.06 MB per 1024-keypoint frame: one direct all-gather per batch (all 7
+xGMI links of a GPU in parallel), not a ring of small messages.
+
+Since round 4 that collective is NATIVE: `ncclAllGather` is called by the engine itself, behind the C ABI
+(csrc/comm_engine.cpp: dani_comm_create / dani_frontend_exchange_boundary / dani_frontend_match_exchanged), on the
+sequence's own HIP stream -- a C++ host can drive it, nothing is synchronised with the host.  `NativeExchange` below is
+the thin Python caller; torch.distributed only carries the 128-byte RCCL id to the ranks (and bench.py's barrier /
+max-reduce).  The torch.distributed forms (`exchange_boundary_features`, `BoundaryExchange`) stay for the gloo rehearsals
+on CPU / on a one-GPU box, where RCCL cannot run several ranks on one device.
 """
 from __future__ import annotations
 
@@ -125,3 +131,34 @@ class BoundaryExchange:
             if self.on_gpu:
                 torch.cuda.current_stream(out.device).synchronize()
         return out
+
+
+class NativeExchange:
+    """The shard-boundary exchange through the engine's own RCCL communicator (include/dani_frontend.h, "the sharded batch's
+    one collective").  Construction is a collective: rank 0 creates the RCCL id, torch.distributed's process group (any
+    backend) carries its 128 bytes to the other ranks, every rank calls dani_comm_create.  start() = pack kernel +
+    ncclAllGather enqueued on the sequence's stream (returns at once); match() = LightGlue of the resident frames with the
+    neighbouring rank's slab as predecessor, ordered behind the collective by that stream."""
+
+    def __init__(self, eng, cap: int, rank: int = 0, world: int = 1):
+        import torch.distributed as dist
+        self.eng, self.cap, self.rank, self.world = eng, cap, rank, world
+        if world > 1:
+            box = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        else:
+            uid = eng.comm_unique_id()
+        eng.comm_create(uid, rank, world)
+
+    def start(self, last_frame: int, sequence: int = 0):
+        return self.eng.frontend_exchange_boundary(last_frame, self.cap, sequence)
+
+    def match(self, nframes: int, sequence: int = 0, lg_threshold: float = 0.05):
+        return self.eng.frontend_match_exchanged(nframes, cap=self.cap, lg_threshold=lg_threshold, sequence=sequence)
+
+    def info(self):
+        return self.eng.comm_info()
+
+    def close(self):
+        self.eng.comm_destroy()

@@ -308,6 +308,38 @@ DANI_API int dani_frontend_export_features(dani_engine* e, int32_t sequence, int
                                            int32_t cap, int32_t* n_out);
 DANI_API int dani_frontend_match_resident(dani_engine* e, int32_t sequence, const float* pred, int32_t pred_on_device, int32_t pred_cap,
                                           float lg_threshold, int32_t* matches, float* scores, int32_t match_cap, int32_t* k_out);
+/* ---- the sharded batch's one collective, native: RCCL all-gather over xGMI (no reference counterpart) ---------
+ *
+ * One engine per process and GPU, `world` processes on one node.  The pair (last frame of rank r-1, first frame of rank r) of a
+ * batch of consecutive frames sharded over the GPUs needs features that live on another GPU (LightGlue pair matching as at
+ * src/Frame.cc:813-860 / src/LGmatcher.cpp:314):
+ *   once:      rank 0: dani_comm_unique_id(id)  -> the 128 bytes reach the other ranks by any means (MPI, a file, a socket,
+ *              torch.distributed's store ...) -> every rank: dani_comm_create(engine, id, 128, rank, world)    [collective]
+ *   per batch: dani_frontend_batch(match_previous = 0)                       YOLO + SuperPoint, features stay in HBM
+ *              dani_frontend_exchange_boundary(seq, B - 1, cap, NULL, ..)    pack kernel -> ncclAllGather on the sequence's stream
+ *              dani_frontend_match_exchanged(seq, ...)                       LightGlue, frame 0 against rank r-1's slab (rank 0:
+ *                                                                            the last rank's slab of the previous batch)
+ * Nothing is synchronised with the host between the three calls: the collective and its consumer are ordered by the sequence's
+ * stream.  librccl is loaded (dlopen) when the first id / communicator is created; DANI_ERR_UNSUPPORTED if it cannot be. */
+#define DANI_COMM_ID_BYTES 128
+DANI_API int dani_comm_unique_id(void* id, int32_t id_bytes);                    /* ncclGetUniqueId; id_bytes >= DANI_COMM_ID_BYTES */
+DANI_API int dani_comm_create(dani_engine* e, const void* id, int32_t id_bytes, int32_t rank, int32_t world);   /* ncclCommInitRank on the engine's GPU */
+DANI_API int dani_comm_destroy(dani_engine* e);                                  /* also done by dani_engine_destroy */
+/* rank / world / RCCL version code / number of all-gathers enqueued so far (any pointer may be NULL) */
+DANI_API int dani_comm_info(dani_engine* e, int32_t* rank, int32_t* world, int32_t* rccl_version, int64_t* collectives);
+/* Pack resident frame `frame` of `sequence` (slab layout of dani_frontend_export_features: count | kpts [cap][2] | desc [cap][256],
+ * unused rows zeroed) and all-gather it: every rank receives [world][1 + cap * 258] floats.  gathered_dev = NULL: into an
+ * engine-owned device buffer of the sequence (what dani_frontend_match_exchanged consumes; *gathered_out, optional, receives its
+ * address -- valid until the sequence's next exchange); otherwise into the caller's DEVICE buffer of that size.  Returns as soon as
+ * the work is enqueued on the sequence's stream.  Every rank must call it, in the same order. */
+DANI_API int dani_frontend_exchange_boundary(dani_engine* e, int32_t sequence, int32_t frame, int32_t cap, float* gathered_dev,
+                                             const float** gathered_out, int32_t* n_out);
+/* dani_frontend_match_resident with the predecessor taken from the sequence's last exchange: rank r > 0 the slab of rank r-1; rank
+ * 0 the LAST rank's slab of the previous exchange (kept on the device across calls and sequences; none before the first one, or
+ * after dani_comm_reset_carry: frame 0 then has no predecessor).  Outputs as dani_frontend_match_resident. */
+DANI_API int dani_frontend_match_exchanged(dani_engine* e, int32_t sequence, float lg_threshold, int32_t* matches, float* scores,
+                                           int32_t match_cap, int32_t* k_out);
+DANI_API int dani_comm_reset_carry(dani_engine* e);
 /* Forget the cached previous frame (start of a new sequence). */
 DANI_API int dani_frontend_reset(dani_engine* e, int32_t sequence);
 /* Complete a descriptor read-back that a defer_desc call left running (no-op otherwise); the cached predecessor is kept.
