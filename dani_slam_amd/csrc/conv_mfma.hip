@@ -62,7 +62,12 @@ __device__ int g_conv_launches;
 // workgroup then gives each range to its own wave(s): 4 / SEG waves along the pixels, SEG along K, every wave a chain
 // 1 / SEG as long, SEG times as many workgroups.  (The deep YOLO levels launch 200-600 workgroups that each walk K = 1152 ...
 // 2304 alone)  SEG = 1: the plain order, everything else in this file.
-template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2, int SEG_ = 1>
+// FW_: flat pixel tiles.  The two deepest YOLOv5s levels are 24 x 40 and 12 x 20 pixels per frame: rectangular tiles of 32-pixel
+// blocks cover them at 83 % (8 x 16 tiles on 24 x 40) and 62 % (4 x 32 on 12 x 20) -- the rest of every MFMA is padding.  With
+// FW_ = the level's width a pixel block is 32 CONSECUTIVE pixels of the frame in row-major order (960 = 30 blocks exactly,
+// 240 = 7.5), a workgroup stages the full-width input rows its pixels touch, and every lane carries its own (row, column)
+// into the operand address -- the k order, hence every result bit, is unchanged.
+template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2, int SEG_ = 1, int FW_ = 0>
 struct Cfg {
   static constexpr int KS = KS_, S = S_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_, ACT = ACT_;
   static constexpr bool POOL = POOL_;
@@ -71,7 +76,9 @@ struct Cfg {
   static constexpr int PAD = (KS == 1) ? 0 : (KS == 3) ? 1 : 2;   // 1x1 p0, 3x3 p1, 6x6 p2 (YOLOv5 stem)
   static constexpr int NCB = NCB_, NCO = 32 * NCB_;   // cout blocks per wave / couts per workgroup
   static constexpr int SEG = SEG_, WPX = 4 / SEG_;     // K segments / waves along the pixels
-  static constexpr int TH = WPX * NPB * PBH, TW = PBW; // WPX waves stacked vertically (output pixels)
+  static constexpr int FW = FW_, NPIX = 32 * WPX * NPB_;   // flat tiles: pixels per workgroup; they span at most MR image rows
+  static constexpr int MR = FW_ ? (NPIX - 2) / FW_ + 2 : 0;
+  static constexpr int TH = FW_ ? MR : WPX * NPB * PBH, TW = FW_ ? FW_ : PBW; // WPX waves stacked vertically (output pixels)
   static constexpr int LROWS = S * (TH - 1) + KS;
   static constexpr int XOFF = (KS == 1) ? 0 : PADX - PAD;          // LDS column of input col (S*px + kx - PAD)
   static constexpr int RS = (XOFF + S * (TW - 1) + KS + 3) / 4 * 4; // LDS row stride (floats), 16-B multiple
@@ -83,6 +90,7 @@ struct Cfg {
   static constexpr int LDS_FLOATS = SEG * (SEG_IN + SEG_W);                             // [seg][input tile] then [seg][weight slab]
   static_assert(SEG == 1 || SEG == 2 || SEG == 4, "K segments");
   static_assert(SEG == 1 || !POOL_, "pooled layers are not split");
+  static_assert(FW_ == 0 || !POOL_, "pooled layers keep rectangular tiles");
   static_assert((SEG - 1) * WPX * 64 * (16 * NCB * NPB + 1) <= LDS_FLOATS, "the segment sums meet in the tile buffers");
   static_assert(PBH * PBW == 32, "a pixel block is one MFMA column block");
   static_assert(!POOL || (PBH == 1 && NPB == 2 && S == 1), "fused pooling needs 2 image rows per wave");
@@ -117,7 +125,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   const int tx = tile % a.tiles_x; tile /= a.tiles_x;
   const int ty = tile % a.tiles_y;
   const int b = tile / a.tiles_y;
-  const int y0 = ty * C::TH, x0 = tx * C::TW;
+  // flat tiles (tiles_y = 1): pixels [p0, p0 + NPIX) of the frame, staged from the full-width rows y0 ..
+  const int p0 = C::FW ? tx * C::NPIX : 0;
+  const int y0 = C::FW ? p0 / (C::FW ? C::FW : 1) : ty * C::TH, x0 = C::FW ? 0 : tx * C::TW;
 
 #ifdef DANI_CONV_STAMPS
   int stamp_row = -1;
@@ -177,6 +187,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 
   const float* bA = sW + seg * C::SEG_W + h * C::NCO + j;
   const float* bB = sIn + seg * C::SEG_IN + (h * C::LROWS + C::S * (wpx * C::NPB * C::PBH + j / C::PBW)) * C::RS + C::S * (j % C::PBW) + C::XOFF;
+  // flat tiles: this lane's pixel of block pb has its own (row, column); a pixel past the frame's end reads the last one's operands
+  const float* bBf[C::NPB];
+  const int npix = a.H * a.W;
+#pragma unroll
+  for (int pb = 0; pb < C::NPB; pb++) {
+    constexpr int fw = C::FW ? C::FW : 1;
+    const int p = min(p0 + (wpx * C::NPB + pb) * 32 + j, npix - 1);
+    bBf[pb] = sIn + seg * C::SEG_IN + (h * C::LROWS + C::S * (p / fw - y0)) * C::RS + C::S * (p % fw) + C::XOFF;
+  }
 
   DANI_PREFETCH(0);
   for (int ch = 0; ch < seg_chunks; ch++) {
@@ -201,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
           for (int cb = 0; cb < C::NCB; cb++) av[cb] = bA[((cp * C::T + ky * C::KS + kx) * 2) * C::NCO + cb * 32];
 #pragma unroll
-          for (int pb = 0; pb < C::NPB; pb++) bv[pb] = bB[(2 * cp * C::LROWS + C::S * pb * C::PBH + ky) * C::RS + kx];
+          for (int pb = 0; pb < C::NPB; pb++)
+            bv[pb] = C::FW ? bBf[pb][(2 * cp * C::LROWS + ky) * C::RS + kx] : bB[(2 * cp * C::LROWS + C::S * pb * C::PBH + ky) * C::RS + kx];
 #pragma unroll
           for (int cb = 0; cb < C::NCB; cb++)
 #pragma unroll
@@ -263,6 +283,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
       }
   } else {
     const float* resb = a.res ? a.res + (size_t)b * a.res_fs : nullptr;
+    // this lane's pixel of block pb: rectangular tiles (y0 + block row, x0 + column) or, flat, pixel p0 + ... of the frame
+    auto pixel = [&](int pb, int& y, int& x) -> bool {
+      if constexpr (C::FW != 0) {
+        const int p = p0 + (wpx * C::NPB + pb) * 32 + j;
+        y = p / C::FW; x = p % C::FW;
+        return p < npix;
+      } else {
+        y = y0 + wpx * C::NPB * C::PBH + pb * C::PBH + j / C::PBW; x = x0 + j % C::PBW;
+        return y < a.H && x < a.W;
+      }
+    };
     // Residual operands first, all of them behind ONE uniform branch: loaded next to their use inside the loop below, each
     // load sits in its own branch with a vmcnt(0) behind it -- 16 dependent round trips per accumulator at the very end of
     // the workgroup (tools/debug/conv_stamps.py: 11-16 k cycles of epilogue in the shortcut layers against 5 k in the others).
@@ -270,8 +301,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     if (C::HAS_RES && resb) {
 #pragma unroll
       for (int pb = 0; pb < C::NPB; pb++) {
-        const int y = y0 + wpx * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
-        const bool ok = y < a.H && x < a.W;
+        int y, x;
+        const bool ok = pixel(pb, y, x);
         const unsigned lane_off = 4u * ((unsigned)(y + a.opady) * (unsigned)a.oWp + (unsigned)(x + PADX) + 4u * (unsigned)h * oplane);
 #pragma unroll
         for (int cb = 0; cb < C::NCB; cb++)
@@ -284,20 +315,48 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
     }
 #pragma unroll
     for (int pb = 0; pb < C::NPB; pb++) {
-      const int y = y0 + wpx * C::NPB * C::PBH + pb * C::PBH + j / C::PBW, x = x0 + j % C::PBW;
-      const bool ok = y < a.H && x < a.W;
+      int y, x;
+      const bool ok = pixel(pb, y, x);
       const unsigned lane_off = 4u * ((unsigned)(y + a.opady) * (unsigned)a.oWp + (unsigned)(x + PADX) + 4u * (unsigned)h * oplane);
+      if constexpr (C::ACT == ACT_SILU) {
+        // The canonical SiLU -- x / (1 + dani_expf(-x)): ~30 dependent instructions per element, IEEE division included -- as 16
+        // INDEPENDENT chains per accumulator in one branch-free block, the stores behind it: with a (predicated) store after every
+        // element each chain sat in its own basic block and ran at its full dependent latency, 5000 cycles per workgroup
+        // (tools/debug/conv_stamps.py), on ~50 launches of YOLO's chain.  Same operations per element: bit-identical.
 #pragma unroll
-      for (int cb = 0; cb < C::NCB; cb++)
+        for (int cb = 0; cb < C::NCB; cb++) {
+          float e[16], v[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          float v = acc[cb][pb][r];
-          if (C::ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
-          if (C::ACT == ACT_SILU) v = v / (1.0f + dani_expf(-v));
-          const int cu = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2);   // uniform; this lane's channel is cu + 4h
-          if constexpr (C::HAS_RES) { if (resb) v = rv[pb][cb][r] + v; }
-          if (ok && cu + 4 * h < a.Cout) at_w(outb + (size_t)cu * oplane, lane_off) = v;
+          for (int r = 0; r < 16; r++) e[r] = dani_expf(-acc[cb][pb][r]);
+#pragma unroll
+          for (int r = 0; r < 16; r++) v[r] = acc[cb][pb][r] / (1.0f + e[r]);
+          if constexpr (C::HAS_RES) {
+            if (resb) {
+#pragma unroll
+              for (int r = 0; r < 16; r++) v[r] = rv[pb][cb][r] + v[r];
+            }
+          }
+          // (the values are pinned HERE: left alone, hipcc sinks each element's ldexp and its whole division into the
+          // predicated block of that element's store, where they run as one dependent chain again)
+#pragma unroll
+          for (int r = 0; r < 16; r++) asm volatile("" : "+v"(v[r]));
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int cu = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2);   // uniform; this lane's channel is cu + 4h
+            if (ok && cu + 4 * h < a.Cout) at_w(outb + (size_t)cu * oplane, lane_off) = v[r];
+          }
         }
+      } else {
+#pragma unroll
+        for (int cb = 0; cb < C::NCB; cb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            float v = acc[cb][pb][r];
+            if (C::ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
+            const int cu = ct * C::NCO + cb * 32 + (r & 3) + 8 * (r >> 2);   // uniform; this lane's channel is cu + 4h
+            if (ok && cu + 4 * h < a.Cout) at_w(outb + (size_t)cu * oplane, lane_off) = v;
+          }
+      }
     }
   }
   STAMP(94, __builtin_readcyclecounter()); STAMP(95, __builtin_amdgcn_s_memrealtime());
@@ -340,6 +399,18 @@ using CfgS2R4SiluK2      = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1, 2>;
 using CfgConv1Blk16sSiluK2 = Cfg<1, 1, 2, 16, 1, 32, ACT_SILU, false, 1, 2>;
 using CfgConv1R4SiluK2   = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 2>;
 using CfgConv1R4K2       = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1, 2>;
+// flat pixel tiles (Cfg::FW) for the 24 x 40 and 12 x 20 levels of YOLOv5s: one 32-pixel block and 32 couts per wave
+//                                KS S        NPB CC  ACT       POOL  NCB SEG FW
+using CfgF40Silu3K2      = Cfg<3, 1, 1, 32, 1, 8, ACT_SILU, false, 1, 2, 40>;
+using CfgF40Silu3S2K2    = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1, 2, 40>;
+using CfgF40Silu1        = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 1, 40>;
+using CfgF40Silu1K2      = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 2, 40>;
+using CfgF40Lin1         = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1, 1, 40>;
+using CfgF20Silu3K4      = Cfg<3, 1, 1, 32, 1, 8, ACT_SILU, false, 1, 4, 20>;
+using CfgF20Silu3S2K2    = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1, 2, 20>;
+using CfgF20Silu1        = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 1, 20>;
+using CfgF20Silu1K2      = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 2, 20>;
+using CfgF20Lin1K2       = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1, 2, 20>;
 // SuperPoint at small batch: narrow (32-cout) twins of the 8x32 tiles and 4x32-pixel tiles
 using CfgRow32nRelu      = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, false, 1>;
 using CfgRow32nReluPool  = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true, 1>;
@@ -352,8 +423,9 @@ static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   a.Cin = L.CinPad; a.Cout = L.Cout; a.H = io.H; a.W = io.W;
   a.iHp = io.iHp; a.iWp = io.iWp; a.ipady = io.ipady; a.oHp = io.oHp; a.oWp = io.oWp; a.opady = io.opady;
   a.in_fs = io.in_fs; a.out_fs = io.out_fs; a.res_fs = io.res_fs;
-  a.tiles_x = (io.W + C::TW - 1) / C::TW;
-  a.tiles_y = (io.H + C::TH - 1) / C::TH;
+  if (C::FW && io.W != C::FW) return false;   // a flat instantiation is built for one level width
+  a.tiles_x = C::FW ? (io.H * io.W + C::NPIX - 1) / C::NPIX : (io.W + C::TW - 1) / C::TW;
+  a.tiles_y = C::FW ? 1 : (io.H + C::TH - 1) / C::TH;
   a.cout_tiles = L.cout_tiles;
   a.nchunks = L.CinPad / C::CC;
   // 32-bit byte offsets inside a frame (epilogue): refused, not launched; the engine reports DANI_ERR_UNSUPPORTED
@@ -406,6 +478,16 @@ bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV3_ROW32N_RELU: return launch_cfg<CfgRow32nRelu>(L, io, B, s, reserve_lds);
     case CONV3_ROW32N_RELU_POOL: return launch_cfg<CfgRow32nReluPool>(L, io, B, s, reserve_lds);
     case CONV3_R4_RELU: return launch_cfg<CfgR4Relu>(L, io, B, s, reserve_lds);
+    case CONV3_F40_SILU_K2: return launch_cfg<CfgF40Silu3K2>(L, io, B, s, reserve_lds);
+    case CONV3S2_F40_SILU_K2: return launch_cfg<CfgF40Silu3S2K2>(L, io, B, s, reserve_lds);
+    case CONV1_F40_SILU: return launch_cfg<CfgF40Silu1>(L, io, B, s, reserve_lds);
+    case CONV1_F40_SILU_K2: return launch_cfg<CfgF40Silu1K2>(L, io, B, s, reserve_lds);
+    case CONV1_F40_LINEAR: return launch_cfg<CfgF40Lin1>(L, io, B, s, reserve_lds);
+    case CONV3_F20_SILU_K4: return launch_cfg<CfgF20Silu3K4>(L, io, B, s, reserve_lds);
+    case CONV3S2_F20_SILU_K2: return launch_cfg<CfgF20Silu3S2K2>(L, io, B, s, reserve_lds);
+    case CONV1_F20_SILU: return launch_cfg<CfgF20Silu1>(L, io, B, s, reserve_lds);
+    case CONV1_F20_SILU_K2: return launch_cfg<CfgF20Silu1K2>(L, io, B, s, reserve_lds);
+    case CONV1_F20_LINEAR_K2: return launch_cfg<CfgF20Lin1K2>(L, io, B, s, reserve_lds);
   }
   return false;
 }

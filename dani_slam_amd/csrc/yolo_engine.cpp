@@ -147,6 +147,29 @@ int yolo_pack_raw(dani_engine* e, YoloWeights* W, const std::string& name, const
     if (conv_variant_kseg(L.variant) != kseg)
       return fail(e, DANI_ERR_UNSUPPORTED, "layer %s (%d -> %d, %dx%d at level %d): no kernel for its %d-segment contraction", name.c_str(), cin, cout, k, k, scale, kseg);
   }
+  // The two deepest levels (24 x 40, 12 x 20) take flat pixel tiles: 32 consecutive pixels of a frame per wave instead of a
+  // rectangle that the level's shape fills at 83 % / 62 % (conv_mfma.hip, Cfg::FW).  Same k order and K segments: bit-identical.
+  // DANI_YOLO_FLAT=0 keeps the rectangular tiles of rounds 2-3 (A/B measurements).
+  static const bool flat_off = getenv("DANI_YOLO_FLAT") && atoi(getenv("DANI_YOLO_FLAT")) == 0;
+  if (!flat_off && scale >= 3 && kYW[3] == 40 && kYW[4] == 20) {
+    ConvVariant f = L.variant;
+    if (scale == 3) {
+      if (k == 3 && s == 1 && kseg == 2) f = CONV3_F40_SILU_K2;
+      else if (k == 3 && s == 2 && kseg == 2) f = CONV3S2_F40_SILU_K2;
+      else if (k == 1 && act && kseg == 1) f = CONV1_F40_SILU;
+      else if (k == 1 && act && kseg == 2) f = CONV1_F40_SILU_K2;
+      else if (k == 1 && !act && kseg == 1) f = CONV1_F40_LINEAR;
+    } else {
+      if (k == 3 && s == 1 && kseg == 4) f = CONV3_F20_SILU_K4;
+      else if (k == 3 && s == 2 && kseg == 2) f = CONV3S2_F20_SILU_K2;
+      else if (k == 1 && act && kseg == 1) f = CONV1_F20_SILU;
+      else if (k == 1 && act && kseg == 2) f = CONV1_F20_SILU_K2;
+      else if (k == 1 && !act && kseg == 2) f = CONV1_F20_LINEAR_K2;
+    }
+    L.variant = f;
+  }
+  if (conv_variant_kseg(L.variant) != kseg)
+    return fail(e, DANI_ERR_UNSUPPORTED, "layer %s: kernel variant %d does not implement its %d-segment contraction", name.c_str(), (int)L.variant, kseg);
   L.Cin = cin; L.Cout = cout; L.ksize = k;
   L.CC = conv_variant_cc(L.variant);
   L.CinPad = round_up(cin, L.CC);

@@ -141,15 +141,25 @@ class NativeExchange:
     neighbouring rank's slab as predecessor, ordered behind the collective by that stream."""
 
     def __init__(self, eng, cap: int, rank: int = 0, world: int = 1):
+        import os
+        import sys
         import torch.distributed as dist
         self.eng, self.cap, self.rank, self.world = eng, cap, rank, world
-        if world > 1:
-            box = [eng.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            uid = box[0]
-        else:
-            uid = eng.comm_unique_id()
-        eng.comm_create(uid, rank, world)
+        # RCCL prints a version banner on STDOUT when a communicator is initialised; bench.py's contract is ONE JSON line there
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if world > 1:
+                box = [eng.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+            else:
+                uid = eng.comm_unique_id()
+            eng.comm_create(uid, rank, world)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
 
     def start(self, last_frame: int, sequence: int = 0):
         return self.eng.frontend_exchange_boundary(last_frame, self.cap, sequence)

