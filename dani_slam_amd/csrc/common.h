@@ -57,8 +57,8 @@ enum ConvVariant {
   CONV3_ROW32N_RELU = 30, CONV3_ROW32N_RELU_POOL = 31, CONV3_R4_RELU = 32,
   // flat pixel tiles (conv_mfma.hip, Cfg::FW): 32 consecutive pixels of a frame per wave, for YOLOv5s' 24 x 40 (F40) and
   // 12 x 20 (F20) levels; K segments as conv_kseg prescribes
-  CONV3_F40_SILU_K2 = 33, CONV3S2_F40_SILU_K2 = 34, CONV1_F40_SILU = 35, CONV1_F40_SILU_K2 = 36, CONV1_F40_LINEAR = 37,
-  CONV3_F20_SILU_K4 = 38, CONV3S2_F20_SILU_K2 = 39, CONV1_F20_SILU = 40, CONV1_F20_SILU_K2 = 41, CONV1_F20_LINEAR_K2 = 42,
+  CONV3_F40_SILU_K2 = 33, CONV3S2_F40_SILU_K2 = 34, CONV1_F40_SILU = 35, CONV1_F40_LINEAR = 36,
+  CONV3_F20_SILU_K4 = 37, CONV3S2_F20_SILU_K2 = 38, CONV1_F20_SILU_K2 = 39,
 };
 
 // Canonical K segmentation of a YOLOv5s convolution (conv_mfma.hip, Cfg::SEG; oracle/sp_oracle.cpp orc_conv2d_ex follows the
@@ -97,13 +97,13 @@ void pack_conv_weights(const float* w_oihw, const float* bias, int Cin, int Cout
 inline int conv_variant_cc(ConvVariant v) {
   return (v == CONV1_BLK16_LINEAR || v == CONV1_ROW32_SILU || v == CONV1_BLK16_SILU || v == CONV1_BLK16S_LINEAR ||
           v == CONV1_BLK16S_SILU || v == CONV1_ROW32N_SILU || v == CONV1_R4_SILU || v == CONV1_R4_LINEAR ||
-          v == CONV1_BLK16S_SILU_K2 || v == CONV1_R4_SILU_K2 || v == CONV1_R4_LINEAR_K2 || v == CONV1_F40_SILU || v == CONV1_F40_SILU_K2 ||
-          v == CONV1_F40_LINEAR || v == CONV1_F20_SILU || v == CONV1_F20_SILU_K2 || v == CONV1_F20_LINEAR_K2) ? 32 : ((v == CONV6S2_ROW32_SILU || v == CONV6S2_ROW32N_SILU) ? 4 : 8);
+          v == CONV1_BLK16S_SILU_K2 || v == CONV1_R4_SILU_K2 || v == CONV1_R4_LINEAR_K2 || v == CONV1_F40_SILU ||
+          v == CONV1_F40_LINEAR || v == CONV1_F20_SILU_K2) ? 32 : ((v == CONV6S2_ROW32_SILU || v == CONV6S2_ROW32N_SILU) ? 4 : 8);
 }
 inline int conv_variant_kseg(ConvVariant v) {
   switch (v) {
     case CONV3_BLK16S_SILU_K2: case CONV3S2_BLK16S_SILU_K2: case CONV3S2_R4_SILU_K2: case CONV1_BLK16S_SILU_K2: case CONV1_R4_SILU_K2: case CONV1_R4_LINEAR_K2:
-    case CONV3_F40_SILU_K2: case CONV3S2_F40_SILU_K2: case CONV1_F40_SILU_K2: case CONV3S2_F20_SILU_K2: case CONV1_F20_SILU_K2: case CONV1_F20_LINEAR_K2: return 2;
+    case CONV3_F40_SILU_K2: case CONV3S2_F40_SILU_K2: case CONV3S2_F20_SILU_K2: case CONV1_F20_SILU_K2: return 2;
     case CONV3_R4_SILU_K4: case CONV3_F20_SILU_K4: return 4;
     default: return 1;
   }

@@ -404,13 +404,10 @@ using CfgConv1R4K2       = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1, 2>;
 using CfgF40Silu3K2      = Cfg<3, 1, 1, 32, 1, 8, ACT_SILU, false, 1, 2, 40>;
 using CfgF40Silu3S2K2    = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1, 2, 40>;
 using CfgF40Silu1        = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 1, 40>;
-using CfgF40Silu1K2      = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 2, 40>;
 using CfgF40Lin1         = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1, 1, 40>;
 using CfgF20Silu3K4      = Cfg<3, 1, 1, 32, 1, 8, ACT_SILU, false, 1, 4, 20>;
 using CfgF20Silu3S2K2    = Cfg<3, 2, 1, 32, 1, 8, ACT_SILU, false, 1, 2, 20>;
-using CfgF20Silu1        = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 1, 20>;
 using CfgF20Silu1K2      = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 2, 20>;
-using CfgF20Lin1K2       = Cfg<1, 1, 1, 32, 1, 32, ACT_NONE, false, 1, 2, 20>;
 // SuperPoint at small batch: narrow (32-cout) twins of the 8x32 tiles and 4x32-pixel tiles
 using CfgRow32nRelu      = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, false, 1>;
 using CfgRow32nReluPool  = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true, 1>;
@@ -481,13 +478,10 @@ bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV3_F40_SILU_K2: return launch_cfg<CfgF40Silu3K2>(L, io, B, s, reserve_lds);
     case CONV3S2_F40_SILU_K2: return launch_cfg<CfgF40Silu3S2K2>(L, io, B, s, reserve_lds);
     case CONV1_F40_SILU: return launch_cfg<CfgF40Silu1>(L, io, B, s, reserve_lds);
-    case CONV1_F40_SILU_K2: return launch_cfg<CfgF40Silu1K2>(L, io, B, s, reserve_lds);
     case CONV1_F40_LINEAR: return launch_cfg<CfgF40Lin1>(L, io, B, s, reserve_lds);
     case CONV3_F20_SILU_K4: return launch_cfg<CfgF20Silu3K4>(L, io, B, s, reserve_lds);
     case CONV3S2_F20_SILU_K2: return launch_cfg<CfgF20Silu3S2K2>(L, io, B, s, reserve_lds);
-    case CONV1_F20_SILU: return launch_cfg<CfgF20Silu1>(L, io, B, s, reserve_lds);
     case CONV1_F20_SILU_K2: return launch_cfg<CfgF20Silu1K2>(L, io, B, s, reserve_lds);
-    case CONV1_F20_LINEAR_K2: return launch_cfg<CfgF20Lin1K2>(L, io, B, s, reserve_lds);
   }
   return false;
 }

@@ -47,7 +47,7 @@ struct LgContext {
   hipEvent_t lnev[2 * LG_LINEARS] = {};   // around every linear_fm launch of a forward pass
   bool aev_ready = false;
   float attn_ms = 0.0f, lin_ms = 0.0f;
-  double attn_flops = 0.0, lin_flops = 0.0;
+  double attn_flops = 0.0, attn_flops_alg = 0.0, lin_flops = 0.0;
 };
 
 
@@ -447,9 +447,16 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
     float tot = 0.0f;
     for (int i = 0; i < 36; i += 2) { float m = 0.0f; (void)hipEventElapsedTime(&m, L->aev[i], L->aev[i + 1]); tot += m; }
     L->attn_ms = tot;
-    double fl = 0.0;   // algorithmic: per launch, per set: 4 heads x (QK^T + PV) = 2 * 2 * nq * nk * 256 flop
-    for (const LgSet& st : L->last_sets) fl += 9.0 * 4.0 * 256.0 * st.n * ((double)st.n + (double)st.partner_n);
-    L->attn_flops = fl;
+    // EXECUTED flop, valid keypoints only: per launch and set 4 heads x (QK^T + PV) = 2 * 2 * nq * nk * 256.  A cross launch forms
+    // K Q^T once per DIRECTION (S and S^T of a pair are each computed), so the executed count of a pair's cross layer is 4 N M d MAC.
+    // ALGORITHMIC: the cross block needs S once, 3 N M d MAC per pair = 3/4 of that (DESIGN.md section 5.2:
+    // why the flash form computes it twice).  Both figures are reported; roofline fractions quote the algorithmic one.
+    double fl = 0.0, fla = 0.0;
+    for (const LgSet& st : L->last_sets) {
+      fl += 9.0 * 4.0 * 256.0 * st.n * ((double)st.n + (double)st.partner_n);
+      fla += 9.0 * 256.0 * st.n * (4.0 * (double)st.n + 3.0 * (double)st.partner_n);
+    }
+    L->attn_flops = fl; L->attn_flops_alg = fla;
     tot = 0.0f;
     for (int i = 0; i < 2 * LG_LINEARS; i += 2) { float m = 0.0f; (void)hipEventElapsedTime(&m, L->lnev[i], L->lnev[i + 1]); tot += m; }
     L->lin_ms = tot;
@@ -578,6 +585,16 @@ int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flo
   if (!e || !L) return DANI_ERR_INVALID;
   if (total_ms) *total_ms = L->attn_ms;
   if (total_flop) *total_flop = L->attn_flops;
+  if (launches) *launches = 18;
+  return DANI_OK;
+}
+
+int dani_lg_attention_profile_ex(dani_engine* e, float* total_ms, double* executed_flop, double* algorithmic_flop, int32_t* launches) {
+  LgContext* L = last_lg(e);
+  if (!e || !L) return DANI_ERR_INVALID;
+  if (total_ms) *total_ms = L->attn_ms;
+  if (executed_flop) *executed_flop = L->attn_flops;
+  if (algorithmic_flop) *algorithmic_flop = L->attn_flops_alg;
   if (launches) *launches = 18;
   return DANI_OK;
 }

@@ -157,14 +157,15 @@ int yolo_pack_raw(dani_engine* e, YoloWeights* W, const std::string& name, const
       if (k == 3 && s == 1 && kseg == 2) f = CONV3_F40_SILU_K2;
       else if (k == 3 && s == 2 && kseg == 2) f = CONV3S2_F40_SILU_K2;
       else if (k == 1 && act && kseg == 1) f = CONV1_F40_SILU;
-      else if (k == 1 && act && kseg == 2) f = CONV1_F40_SILU_K2;
       else if (k == 1 && !act && kseg == 1) f = CONV1_F40_LINEAR;
+      // (1x1 with two K segments -- model.13's cv1|cv2 -- keeps the 8x16 tiles: 35.7 us against 38.5 flat; a 1x1 layer gains
+      // nothing from full-width rows, it only stages more of them.  profiles/r04_yolo_chain_alone_flat*.txt)
     } else {
       if (k == 3 && s == 1 && kseg == 4) f = CONV3_F20_SILU_K4;
       else if (k == 3 && s == 2 && kseg == 2) f = CONV3S2_F20_SILU_K2;
-      else if (k == 1 && act && kseg == 1) f = CONV1_F20_SILU;
-      else if (k == 1 && act && kseg == 2) f = CONV1_F20_SILU_K2;
-      else if (k == 1 && !act && kseg == 2) f = CONV1_F20_LINEAR_K2;
+      // 1x1 layers at 12 x 20: flat tiles only where they still launch two workgroups per CU (512 outputs); the 256-output
+      // ones would drop to 128-256 workgroups of 64-128 pixels (15.5 us against 13.1, 18.8 against 17.9)
+      else if (k == 1 && act && kseg == 2 && cout >= 512) f = CONV1_F20_SILU_K2;
     }
     L.variant = f;
   }

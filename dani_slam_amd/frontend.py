@@ -101,6 +101,7 @@ def load_library():
     lib.dani_lg_match_groups.argtypes = [C.c_void_p, _f, _f, C.c_int32, _f, _f, C.c_int32, C.c_int32, _i32, _i32, _i32, _i32, _f, _f,
                                          C.c_float, _i32, _f, _i32, C.c_int32]
     lib.dani_lg_attention_profile.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), _i32]
+    lib.dani_lg_attention_profile_ex.argtypes = [C.c_void_p, _f, C.POINTER(C.c_double), C.POINTER(C.c_double), _i32]
     lib.dani_vocab_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32, _i32, _f, C.POINTER(C.c_double), _i32, C.POINTER(C.c_void_p)]
     lib.dani_vocab_destroy.argtypes = [C.c_void_p]
     lib.dani_vocab_destroy.restype = None
@@ -415,10 +416,11 @@ class Engine:
         self._check(self.lib.dani_lg_set_kernel_option(name.encode(), int(value)))
 
     def lg_attention_profile(self):
-        """(total ms, total algorithmic flop, launches) of the attention kernel in the last LightGlue call (profiling on)."""
-        ms = C.c_float(0); fl = C.c_double(0); n = C.c_int32(0)
-        self._check(self.lib.dani_lg_attention_profile(self.h, C.byref(ms), C.byref(fl), C.byref(n)))
-        return ms.value, fl.value, n.value
+        """(total ms, EXECUTED flop, launches, ALGORITHMIC flop) of the attention launches of the last LightGlue call (profiling on):
+        a cross launch computes K Q^T once per direction; SURVEY.md section 8d counts a pair's cross scores once."""
+        ms = C.c_float(0); fl = C.c_double(0); fa = C.c_double(0); n = C.c_int32(0)
+        self._check(self.lib.dani_lg_attention_profile_ex(self.h, C.byref(ms), C.byref(fl), C.byref(fa), C.byref(n)))
+        return ms.value, fl.value, n.value, fa.value
 
     def lg_linear_profile(self):
         """(total ms, total algorithmic flop, launches) of the linear_fm launches in the last LightGlue call (profiling on)."""

@@ -212,6 +212,10 @@ DANI_API int dani_lg_match_groups(dani_engine* e, const float* kpts0, const floa
 /* With dani_set_profiling(e, 1): summed duration (HIP events on the engine's stream) and algorithmic FLOP of the 18
  * attention-kernel launches of the last LightGlue call on this thread (bench.py roofline of the dominant kernel). */
 DANI_API int dani_lg_attention_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches);
+/* The same with both FLOP counts: `executed` as above (a cross launch forms K Q^T once per direction: 4 N M d MAC per pair and layer),
+ * `algorithmic` = SURVEY.md section 8d's count, in which a pair's cross block needs its score matrix once (3 N M d MAC).  bench.py
+ * quotes roofline fractions on the algorithmic count and reports the executed one beside it. */
+DANI_API int dani_lg_attention_profile_ex(dani_engine* e, float* total_ms, double* executed_flop, double* algorithmic_flop, int32_t* launches);
 /* same for the feature-major linear layers of the forward pass (55 launches: 6 per layer + final_proj) */
 DANI_API int dani_lg_linear_profile(dani_engine* e, float* total_ms, double* total_flop, int32_t* launches);
 
