@@ -59,6 +59,8 @@ enum ConvVariant {
   // 12 x 20 (F20) levels; K segments as conv_kseg prescribes
   CONV3_F40_SILU_K2 = 33, CONV3S2_F40_SILU_K2 = 34, CONV1_F40_SILU = 35, CONV1_F40_LINEAR = 36,
   CONV3_F20_SILU_K4 = 37, CONV3S2_F20_SILU_K2 = 38, CONV1_F20_SILU_K2 = 39,
+  // SuperPoint's conv1b with conv1a computed inside the kernel from the u8 image (conv_mfma.hip, Cfg::F1A)
+  CONV3_ROW32_RELU_POOL_F1A = 40, CONV3_ROW32N_RELU_POOL_F1A = 41,
 };
 
 // Canonical K segmentation of a YOLOv5s convolution (conv_mfma.hip, Cfg::SEG; oracle/sp_oracle.cpp orc_conv2d_ex follows the
@@ -78,6 +80,9 @@ struct ConvIO {
   int H = 0, W = 0;                      // conv output dims (before fused pooling)
   int iHp = 0, iWp = 0, ipady = PADY, oHp = 0, oWp = 0, opady = PADY;
   size_t in_fs = 0, out_fs = 0, res_fs = 0;
+  // Cfg::F1A variants only: the u8 image (device) the layer's input is computed from, and conv1a's raw weights / bias
+  const uint8_t* img = nullptr; int img_stride = 0; size_t img_fs = 0;
+  const float* w1a = nullptr; const float* b1a = nullptr;
 };
 
 struct ConvLayerPlan {
@@ -108,7 +113,7 @@ inline int conv_variant_kseg(ConvVariant v) {
     default: return 1;
   }
 }
-inline int conv_variant_nco(ConvVariant v) { return v >= CONV3_BLK16S_RELU ? 32 : 64; }   // couts per workgroup
+inline int conv_variant_nco(ConvVariant v) { return (v >= CONV3_BLK16S_RELU && v != CONV3_ROW32_RELU_POOL_F1A) ? 32 : 64; }   // couts per workgroup
 // the small-grid twin of a 16x16-tile variant (or the variant itself)
 inline ConvVariant conv_small_variant(ConvVariant v) {
   switch (v) {
@@ -127,6 +132,9 @@ void launch_conv1a(const uint8_t* img, int B, int H, int W, int stride, size_t i
                    const float* bias /*64*/, const ActDesc& out, hipStream_t s);
 // false = shape outside the kernel's 32-bit addressing contract: nothing was launched (DANI_ERR_UNSUPPORTED upstream)
 bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& out, int B, hipStream_t s, int reserve_lds = 0);
+// conv1b computing conv1a on the fly (L.variant is an F1A variant): `in` gives the geometry only, the data comes from the image
+bool launch_conv_mfma_f1a(const ConvLayerPlan& L, const uint8_t* img, int img_stride, size_t img_fs, const float* w1a, const float* b1a,
+                          const ActDesc& in, const ActDesc& out, int B, hipStream_t s, int reserve_lds = 0);
 bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds = 0);
 const char* conv_kernel_name(ConvVariant v);
 

@@ -40,6 +40,9 @@ struct ConvArgs {
   size_t in_fs, out_fs, res_fs;   // per-frame strides in floats (tensors may be channel slices of concat buffers)
   int tiles_x, tiles_y, cout_tiles, nchunks;
   int ntiles, tiles_base, tiles_rem;   // pixel tiles of the launch (B * tiles_y * tiles_x) = 8 * tiles_base + tiles_rem
+  // Cfg::F1A (conv1b with conv1a computed on the fly): the u8 image instead of `in`, and conv1a's raw parameters
+  const uint8_t* img; int img_stride; size_t img_fs;
+  const float* w1a; const float* b1a;   // [64][9], [64]
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2 };
@@ -67,8 +70,15 @@ __device__ int g_conv_launches;
 // FW_ = the level's width a pixel block is 32 CONSECUTIVE pixels of the frame in row-major order (960 = 30 blocks exactly,
 // 240 = 7.5), a workgroup stages the full-width input rows its pixels touch, and every lane carries its own (row, column)
 // into the operand address -- the k order, hence every result bit, is unchanged.
-template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2, int SEG_ = 1, int FW_ = 0>
+// F1A_: conv1b computes its own input.  SuperPoint's conv1a (1 -> 64 channels, 9 taps, ReLU; /root/reference/src/SuperPoint.cpp:58
+// with detect()'s u8 -> f32 / 255, :192-193) is 0.35 GFLOP that used to write 629 MB per 8-frame step for conv1b to read back
+// (profiles/r03_pmc_summary.json: 661 MB of HBM traffic per conv1a_kernel launch).  With F1A_ a conv1b workgroup keeps the
+// (TH + 4) x (TW + 4) u8 window of its tile in LDS and every thread forms the haloed conv1a values of the next 8-channel chunk on
+// the vector ALU -- 9 fmaf per value in conv1a_kernel's own order, so bit for bit what that kernel stores -- under the current
+// chunk's MFMAs.  Positions outside the image are conv1b's zero padding (NOT conv1a of a padded image).
+template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2, int SEG_ = 1, int FW_ = 0, bool F1A_ = false>
 struct Cfg {
+  static constexpr bool F1A = F1A_;
   static constexpr int KS = KS_, S = S_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_, ACT = ACT_;
   static constexpr bool POOL = POOL_;
   static constexpr int T = KS * KS;
@@ -87,7 +97,11 @@ struct Cfg {
   static constexpr int W_F4 = CC * T * NCO / 4;         // per K segment
   static constexpr int NI = (SEG * IN_F4 + 255) / 256, NW = (SEG * W_F4 + 255) / 256;   // staging float4 per thread, all segments
   static constexpr int SEG_IN = CC * LROWS * RS, SEG_W = CC * T * NCO;                  // LDS floats per segment
-  static constexpr int LDS_FLOATS = SEG * (SEG_IN + SEG_W);                             // [seg][input tile] then [seg][weight slab]
+  static constexpr int IMG_RS = (TW + 4 + 3) / 4 * 4, IMG_ROWS = LROWS + 2;             // F1A: u8 window of the tile, as f32 / 255
+  static constexpr int HALO_W = S * (TW - 1) + KS, HALO_N = LROWS * HALO_W;             // F1A: haloed positions of one input channel
+  static constexpr int NPOS = (HALO_N + 255) / 256;                                     // F1A: positions per thread
+  static constexpr int LDS_FLOATS = SEG * (SEG_IN + SEG_W) + (F1A_ ? IMG_ROWS * IMG_RS : 0);   // [seg][input tile], [seg][weight slab] (, image window)
+  static_assert(!F1A_ || (KS_ == 3 && S_ == 1 && SEG_ == 1 && FW_ == 0 && CC_ == 8), "conv1a feeds a plain 3x3 stride-1 layer");
   static_assert(SEG == 1 || SEG == 2 || SEG == 4, "K segments");
   static_assert(SEG == 1 || !POOL_, "pooled layers are not split");
   static_assert(FW_ == 0 || !POOL_, "pooled layers keep rectangular tiles");
@@ -173,16 +187,62 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
       for (int pb = 0; pb < C::NPB; pb++) acc[cb][pb][r] = bv;
     }
 
-  f32x4 pin[C::NI], pw[C::NW];
+  f32x4 pin[C::F1A ? 1 : C::NI], pw[C::NW];
+  // F1A: this thread's haloed positions (row r, column cx of the LROWS x HALO_W grid), their 3 x 3 image windows and the
+  // conv1a values of the chunk being prepared
+  float win[C::F1A ? C::NPOS : 1][9], nv[C::F1A ? C::NPOS : 1][C::CC];
+  int lpos[C::F1A ? C::NPOS : 1];       // LDS offset of the position inside a channel's tile, or -1
+  bool inimg[C::F1A ? C::NPOS : 1];
+  if constexpr (C::F1A) {
+    float* sImg = lds + C::SEG * (C::SEG_IN + C::SEG_W);
+    const uint8_t* im = a.img + (size_t)b * a.img_fs;
+    for (int e = tid; e < C::IMG_ROWS * (C::TW + 4); e += 256) {
+      const int r = e / (C::TW + 4), c = e % (C::TW + 4);
+      const int iy = y0 - 2 + r, ix = x0 - 2 + c;
+      sImg[r * C::IMG_RS + c] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? (float)im[(size_t)iy * a.img_stride + ix] / 255.0f : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < C::NPOS; u++) {
+      const int pos = tid + 256 * u;
+      const bool has = pos < C::HALO_N;
+      const int r = has ? pos / C::HALO_W : 0, cx = has ? pos % C::HALO_W : 0;
+      lpos[u] = has ? r * C::RS + C::XOFF + cx : -1;
+      const int iy = y0 - 1 + r, ix = x0 - 1 + cx;                     // conv1b's input coordinate of this position
+      inimg[u] = has && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+#pragma unroll
+      for (int t = 0; t < 9; t++) win[u][t] = sImg[(r + t / 3) * C::IMG_RS + cx + t % 3];
+    }
+  }
+  // conv1a of chunk ch_ at this thread's positions: acc = bias, taps in (ky, kx) order, ReLU (conv1a_kernel's arithmetic)
+  auto conv1a_chunk = [&](int ch_) {
+    if constexpr (C::F1A) {
+#pragma unroll
+      for (int cc = 0; cc < C::CC; cc++) {
+        const float* wv = a.w1a + (size_t)(ch_ * C::CC + cc) * 9;      // uniform: scalar loads
+        const float bv = a.b1a[ch_ * C::CC + cc];
+#pragma unroll
+        for (int u = 0; u < C::NPOS; u++) {
+          float v = bv;
+#pragma unroll
+          for (int t = 0; t < 9; t++) v = __builtin_fmaf(win[u][t], wv[t], v);
+          nv[u][cc] = (inimg[u] && v > 0.0f) ? v : 0.0f;
+        }
+      }
+    }
+  };
   // global -> VGPR prefetch of chunk `ch` (loads are unconditional: tail lanes re-read element 0)
 #define DANI_PREFETCH(ch_)                                                                   \
   {                                                                                          \
-    const float* src_ = inb + (size_t)(ch_) * C::CC * iplane;                                \
-    _Pragma("unroll") for (int t = 0; t < C::NI; t++)                                        \
-      pin[t] = *reinterpret_cast<const f32x4*>(src_ + goff[t]);                              \
+    if constexpr (!C::F1A) {                                                                 \
+      const float* src_ = inb + (size_t)(ch_) * C::CC * iplane;                              \
+      _Pragma("unroll") for (int t = 0; t < C::NI; t++)                                      \
+        pin[t] = *reinterpret_cast<const f32x4*>(src_ + goff[t]);                            \
+    }                                                                                        \
     const f32x4* wsrc_ = reinterpret_cast<const f32x4*>(wt + (size_t)(ch_) * (C::W_F4 * 4)); \
     _Pragma("unroll") for (int t = 0; t < C::NW; t++)                                        \
       pw[t] = wsrc_[woff[t]];                                                                \
+    conv1a_chunk(ch_);                                                                       \
   }
 
   const float* bA = sW + seg * C::SEG_W + h * C::NCO + j;
@@ -200,9 +260,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   DANI_PREFETCH(0);
   for (int ch = 0; ch < seg_chunks; ch++) {
     __syncthreads();  // everyone finished reading the previous chunk
+    if constexpr (C::F1A) {
 #pragma unroll
-    for (int t = 0; t < C::NI; t++)
-      if (tid + 256 * t < C::SEG * C::IN_F4) reinterpret_cast<f32x4*>(sIn)[tid + 256 * t] = pin[t];
+      for (int u = 0; u < C::NPOS; u++)
+        if (lpos[u] >= 0) {
+#pragma unroll
+          for (int cc = 0; cc < C::CC; cc++) sIn[cc * C::LROWS * C::RS + lpos[u]] = nv[u][cc];
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < C::NI; t++)
+        if (tid + 256 * t < C::SEG * C::IN_F4) reinterpret_cast<f32x4*>(sIn)[tid + 256 * t] = pin[t];
+    }
 #pragma unroll
     for (int t = 0; t < C::NW; t++)
       if (tid + 256 * t < C::SEG * C::W_F4) reinterpret_cast<f32x4*>(sW)[tid + 256 * t] = pw[t];
@@ -412,6 +481,9 @@ using CfgF20Silu1K2      = Cfg<1, 1, 1, 32, 1, 32, ACT_SILU, false, 1, 2, 20>;
 using CfgRow32nRelu      = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, false, 1>;
 using CfgRow32nReluPool  = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true, 1>;
 using CfgR4Relu          = Cfg<3, 1, 1, 32, 1, 8, ACT_RELU, false, 1>;
+// conv1b with conv1a computed inside (Cfg::F1A): the pooled 8x32 tile at 64 and at 32 couts per workgroup
+using CfgRow32ReluPoolF1A  = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true, 2, 1, 0, true>;
+using CfgRow32nReluPoolF1A = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true, 1, 1, 0, true>;
 
 template <class C>
 static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds) {
@@ -420,6 +492,8 @@ static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   a.Cin = L.CinPad; a.Cout = L.Cout; a.H = io.H; a.W = io.W;
   a.iHp = io.iHp; a.iWp = io.iWp; a.ipady = io.ipady; a.oHp = io.oHp; a.oWp = io.oWp; a.opady = io.opady;
   a.in_fs = io.in_fs; a.out_fs = io.out_fs; a.res_fs = io.res_fs;
+  a.img = io.img; a.img_stride = io.img_stride; a.img_fs = io.img_fs; a.w1a = io.w1a; a.b1a = io.b1a;
+  if (C::F1A && (!io.img || !io.w1a || !io.b1a || L.CinPad != 64)) return false;   // the fused layer reads the image, not `in`
   if (C::FW && io.W != C::FW) return false;   // a flat instantiation is built for one level width
   a.tiles_x = C::FW ? (io.H * io.W + C::NPIX - 1) / C::NPIX : (io.W + C::TW - 1) / C::TW;
   a.tiles_y = C::FW ? 1 : (io.H + C::TH - 1) / C::TH;
@@ -475,6 +549,8 @@ bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV3_ROW32N_RELU: return launch_cfg<CfgRow32nRelu>(L, io, B, s, reserve_lds);
     case CONV3_ROW32N_RELU_POOL: return launch_cfg<CfgRow32nReluPool>(L, io, B, s, reserve_lds);
     case CONV3_R4_RELU: return launch_cfg<CfgR4Relu>(L, io, B, s, reserve_lds);
+    case CONV3_ROW32_RELU_POOL_F1A: return launch_cfg<CfgRow32ReluPoolF1A>(L, io, B, s, reserve_lds);
+    case CONV3_ROW32N_RELU_POOL_F1A: return launch_cfg<CfgRow32nReluPoolF1A>(L, io, B, s, reserve_lds);
     case CONV3_F40_SILU_K2: return launch_cfg<CfgF40Silu3K2>(L, io, B, s, reserve_lds);
     case CONV3S2_F40_SILU_K2: return launch_cfg<CfgF40Silu3S2K2>(L, io, B, s, reserve_lds);
     case CONV1_F40_SILU: return launch_cfg<CfgF40Silu1>(L, io, B, s, reserve_lds);
@@ -493,6 +569,17 @@ bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& 
   io.H = in.H; io.W = in.W;   // stride-1 layers: conv output dims == input dims (pooling happens in the epilogue)
   io.iHp = in.Hp; io.iWp = in.Wp; io.ipady = in.pady; io.oHp = out.Hp; io.oWp = out.Wp; io.opady = out.pady;
   io.in_fs = in.frame_stride(); io.out_fs = out.frame_stride(); io.res_fs = 0;
+  return launch_conv_io(L, io, B, s, reserve_lds);
+}
+
+bool launch_conv_mfma_f1a(const ConvLayerPlan& L, const uint8_t* img, int img_stride, size_t img_fs, const float* w1a, const float* b1a,
+                          const ActDesc& in, const ActDesc& out, int B, hipStream_t s, int reserve_lds) {
+  ConvIO io;
+  io.in = in.p; io.out = out.p; io.res = nullptr;
+  io.H = in.H; io.W = in.W;
+  io.iHp = in.Hp; io.iWp = in.Wp; io.ipady = in.pady; io.oHp = out.Hp; io.oWp = out.Wp; io.opady = out.pady;
+  io.in_fs = in.frame_stride(); io.out_fs = out.frame_stride(); io.res_fs = 0;
+  io.img = img; io.img_stride = img_stride; io.img_fs = img_fs; io.w1a = w1a; io.b1a = b1a;
   return launch_conv_io(L, io, B, s, reserve_lds);
 }
 

@@ -70,6 +70,8 @@ struct Context {
     float* h_cand = nullptr;          // pinned
     int32_t* h_cand_count = nullptr;  // pinned
     uint8_t* d_level_img = nullptr;   // level > 0: this level's image [B][H][W] (resized from level - 1)
+    const uint8_t* last_img = nullptr; int last_stride = 0, last_B = 0; size_t last_frame = 0;   // the last call's level image (device)
+    bool act0_valid = false;          // act[0] (conv1a) holds the last call's activation (false when conv1b computed it on the fly)
   };
   std::vector<Level> lv;
   int32_t* d_boxes = nullptr;

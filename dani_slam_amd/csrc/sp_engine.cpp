@@ -194,6 +194,10 @@ int dani_finalize_weights(dani_engine* e) {
       const bool pooled = L.variant == CONV3_ROW32_RELU_POOL;
       if (wgs < small_wgs) L.variant = pooled ? CONV3_ROW32N_RELU_POOL : (2 * wgs < small_wgs ? CONV3_R4_RELU : CONV3_ROW32N_RELU);
     }
+    if (i == 1) {   // conv1b computes conv1a itself from the u8 image (conv_mfma.hip, Cfg::F1A); DANI_SP_FUSE_1A=0: the two launches of rounds 1-3
+      static const bool fuse_off = getenv("DANI_SP_FUSE_1A") && atoi(getenv("DANI_SP_FUSE_1A")) == 0;
+      if (!fuse_off) L.variant = L.variant == CONV3_ROW32_RELU_POOL ? CONV3_ROW32_RELU_POOL_F1A : (L.variant == CONV3_ROW32N_RELU_POOL ? CONV3_ROW32N_RELU_POOL_F1A : L.variant);
+    }
     L.Cin = d.cin; L.Cout = d.cout; L.ksize = d.k; L.CinPad = d.cin;
     L.CC = conv_variant_cc(L.variant);
     const int nco = conv_variant_nco(L.variant);
@@ -291,8 +295,10 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
         limg = L.d_level_img; lstride = L.W; lframe = (size_t)L.W * L.H;
       }
       const bool lprof = prof && l == 0;
+      const bool fused1a = e->plan[1].variant == CONV3_ROW32_RELU_POOL_F1A || e->plan[1].variant == CONV3_ROW32N_RELU_POOL_F1A;
+      L.last_img = limg; L.last_stride = lstride; L.last_frame = lframe; L.last_B = B; L.act0_valid = !fused1a;
       if (lprof) HIP_TRY(e, hipEventRecord(c->lev[0], s));
-      launch_conv1a(limg, B, L.H, L.W, lstride, lframe, e->w1a, e->b1a, L.act[0], s);
+      if (!fused1a) launch_conv1a(limg, B, L.H, L.W, lstride, lframe, e->w1a, e->b1a, L.act[0], s);   // fused: conv1b forms it on the fly
       if (lprof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
       const int src_of[12] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10};
       // One or two frames: the detector head (convPa, convPb, softmax) and the descriptor head (convDa, convDb, norm) are
@@ -308,7 +314,10 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
           HIP_TRY(e, hipEventRecord(c->ev_fork0, s));
           HIP_TRY(e, hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
         }
-        if (!launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, si, reserve)) {
+        const bool launched = (i == 1 && fused1a)
+            ? launch_conv_mfma_f1a(e->plan[1], limg, lstride, lframe, e->w1a, e->b1a, L.act[0], L.act[1], B, si, reserve)
+            : launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, si, reserve);
+        if (!launched) {
           (void)hipStreamSynchronize(s);
           if (fork) (void)hipStreamSynchronize(c->stream2);
           return fail(e, DANI_ERR_UNSUPPORTED, "%s at %dx%d: activation tensor exceeds the conv kernel's 32-bit addressing range", kSp[i].name, L.W, L.H);
@@ -552,6 +561,15 @@ int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, in
   const size_t need = (size_t)a.C * a.H * a.W;
   if ((size_t)count < need) return fail(e, DANI_ERR_CAPACITY, "layer %d needs %zu floats", layer, need);
   HIP_TRY(e, hipSetDevice(e->device));
+  if (layer == 0 && !c->lv[0].act0_valid) {
+    // conv1a's activation never reaches HBM when conv1b computes it on the fly: the test hook runs the stand-alone kernel on the
+    // last call's image (still in the staging buffer, or at the caller's device pointer)
+    Context::Level& L0 = c->lv[0];
+    if (!L0.last_img || b >= L0.last_B) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
+    launch_conv1a(L0.last_img, L0.last_B, L0.H, L0.W, L0.last_stride, L0.last_frame, e->w1a, e->b1a, L0.act[0], c->stream);
+    HIP_TRY(e, hipGetLastError());
+    L0.act0_valid = true;
+  }
   float* tmp = nullptr;
   HIP_TRY(e, hipMalloc((void**)&tmp, need * 4));
   launch_copy_layer_dense(a, b, tmp, c->stream);
