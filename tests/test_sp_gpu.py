@@ -94,27 +94,44 @@ def test_other_params_and_thresholds(engine, sp_weights, oracle_frames):
         assert np.array_equal(r["desc"], ref["desc"])
 
 
-def test_dense_frames_have_no_candidate_limit(engine, sp_weights):
-    """A frame on which EVERY pixel of every cell is a candidate (thresholds 0: prob > 0 holds everywhere) -- 204 cells x up
-    to 1848 pixels, the 6-px overlap strips counted twice (quirk Q5): ~350 k candidates where rounds 1-3 answered
-    DANI_ERR_CAPACITY above 32 768.  The reference processes any count (vToDistributeKeys grows,
-    /root/reference/src/SPextractor.cpp:248-312); so does the engine, with boxes and in a batch next to a sparse frame."""
-    img = synth.frame(1)
-    ref = oracle.sp_extract(img, sp_weights, nfeatures=1024, iniTh=0.0, minTh=0.0)
-    r = engine.sp_extract_batch(img[None], nfeatures=1024, iniTh=0.0, minTh=0.0)[0]
-    _, _, cand = engine.sp_debug_fetch(0, 480, 640, cand_cap=1 << 19)
+def test_dense_frames_have_no_candidate_limit(sp_weights):
+    """A frame on which EVERY pixel of every cell is a candidate -- a detector head with zero weights gives the flat probability
+    map 1/65 = 0.0154 > iniTh = 0.015 -- i.e. 204 cells x up to 1848 pixels with the 6-px overlap strips counted twice (quirk
+    Q5): 361 856 candidates where rounds 1-3 answered DANI_ERR_CAPACITY above 32 768.  The reference processes any count
+    (vToDistributeKeys grows, /root/reference/src/SPextractor.cpp:248-312); so does the engine, with boxes and in a batch next
+    to a second frame."""
     from dani_slam_amd import frontend
+    w = dict(sp_weights)
+    w["convPb.weight"] = np.zeros_like(w["convPb.weight"]); w["convPb.bias"] = np.zeros_like(w["convPb.bias"])
+    e = frontend.Engine(device=0, max_batch=2, max_width=640, max_height=480, weights=w)
+    img = synth.frame(1)
+    ref = oracle.sp_extract(img, w, nfeatures=1024)
+    r = e.sp_extract_batch(img[None], nfeatures=1024)[0]
+    prob, _, cand = e.sp_debug_fetch(0, 480, 640, cand_cap=1 << 19)
+    assert np.all(prob == np.float32(1.0) / np.float32(65.0))
     cells = frontend.host_cell_grid(640, 480)      # (iniX, maxX, iniY, maxY, offX, offY) of the non-skipped cells
-    assert len(cand) == int(((cells[:, 1] - cells[:, 0]) * (cells[:, 3] - cells[:, 2])).sum()) > 300_000      # every cell pixel
+    assert len(cand) == int(((cells[:, 1] - cells[:, 0]) * (cells[:, 3] - cells[:, 2])).sum()) == 361856      # every cell pixel
     assert np.array_equal(r["kpts"], ref["kpts"]) and np.array_equal(r["resp"], ref["resp"])
     assert np.array_equal(r["desc"], ref["desc"])
     boxes = [(100, 60, 300, 200), (500, 300, 90, 120)]
-    refb = oracle.sp_extract(img, sp_weights, nfeatures=2000, iniTh=0.0, minTh=0.0, boxes=boxes)
-    two = engine.sp_extract_batch(np.stack([img, synth.frame(2)]), nfeatures=2000, iniTh=0.0, minTh=0.0,
-                                  boxes=[np.array(boxes, np.int32), np.zeros((0, 4), np.int32)])
+    refb = oracle.sp_extract(img, w, nfeatures=2000, boxes=boxes)
+    ref2 = oracle.sp_extract(synth.frame(2), w, nfeatures=2000)
+    two = e.sp_extract_batch(np.stack([img, synth.frame(2)]), nfeatures=2000,
+                             boxes=[np.array(boxes, np.int32), np.zeros((0, 4), np.int32)])
     assert np.array_equal(two[0]["kpts"], refb["kpts"]) and np.array_equal(two[0]["desc"], refb["desc"])
-    ref2 = oracle.sp_extract(synth.frame(2), sp_weights, nfeatures=2000, iniTh=0.0, minTh=0.0)
     assert np.array_equal(two[1]["kpts"], ref2["kpts"]) and np.array_equal(two[1]["desc"], ref2["desc"])
+    assert len({tuple(k) for k in refb["kpts"].tolist()} & {(float(x), float(y)) for x in range(100, 400) for y in range(60, 260)}) == 0
+    # the fused call's host-side cull sees the same dense list (single level: candidates are fetched without the boxes)
+    wf = dict(w); wf.update(synth.lightglue_weights(0)); wf.update(synth.yolo_weights(0))
+    e2 = frontend.Engine(device=0, max_batch=1, weights=wf)
+    e2.yolo_set_classes(synth.COCO_NAMES, synth.DYNAMIC_NAMES)
+    from oracle import yolo_oracle as yo
+    bgr = synth.frame_bgr(1)
+    o = e2.frontend_batch(img[None], bgr[None], nfeatures=1024, match_previous=False)[0]
+    dyn = yo.detect(wf, bgr)[2]
+    refd = oracle.sp_extract(img, w, nfeatures=1024, boxes=dyn)
+    assert np.array_equal(o["kpts"], refd["kpts"]) and np.array_equal(o["desc"], refd["desc"])
+    e.close(); e2.close()
 
 
 def test_non_contiguous_stride_and_smaller_image(sp_weights):
