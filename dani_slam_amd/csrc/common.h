@@ -210,6 +210,13 @@ bool launch_linear_fm(const float* x0, int K0, const float* x1, int K1, const fl
                       int rot_rows, float alpha, hipStream_t s, const float* w_rs = nullptr);
 void pack_linear_rs_host(const float* w_row_major, int out, int in, float* dst);   // [out][in] -> lin_rs.h layout (out * in floats)
 void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s);
+// ffn_chain.h: ffn.0 -> LayerNorm + GELU -> ffn.3 (+ residual) -> the next block's projection for the 16-token blocks [0, nblocks) in
+// one launch, activations resident in registers.  p0 / p3 / pd: pack_chain_weights_host with role 1 / 2 / 3; biases unpadded.
+// pd = nullptr: no projection.  false = shape outside the kernel's contract (nothing launched).
+bool launch_ffn_chain_fm(float* x, const float* ctx, const float* p0, const float* b0, const float* gamma, const float* beta,
+                         const float* p3, const float* b3, const float* pd, const float* bd, int OUTD, float* y, const float* cosb,
+                         const float* sinb, int rot_rows, float alpha, int nblocks, int ld, hipStream_t s);
+void pack_chain_weights_host(const float* w_row_major, int out, int in, int role, float* dst);   // role 1 / 2 / 3, see lg_engine.cpp lg_pack_raw
 void launch_posenc(const LgSet* sets, int nsets, int max_span, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s);
 void launch_desc_to_fm(const LgSet* sets, int nsets, int max_span, float* x, int ld, hipStream_t s);
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,

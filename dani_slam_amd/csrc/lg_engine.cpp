@@ -8,13 +8,13 @@ using namespace dani::eng;
 // ================================================================================================
 // LightGlue
 // ================================================================================================
-namespace dani { extern std::atomic<int> g_lin_force_rs, g_attn_force; }
+namespace dani { extern std::atomic<int> g_lin_force_rs, g_attn_force, g_ffn_chain; }
 namespace dani {
 namespace eng {
 
 constexpr int LG_LAYERS = 9;
 
-struct LgLinear { float* w = nullptr; float* b = nullptr; void* w3 = nullptr; float* wrs = nullptr; int out = 0, in = 0; };   // w3: bf16x3 split of w (lg_x3.hip); wrs: lin_rs.h layout
+struct LgLinear { float* w = nullptr; float* b = nullptr; void* w3 = nullptr; float* wrs = nullptr; float* pc = nullptr; float* braw = nullptr; int out = 0, in = 0; };   // w3: bf16x3 split of w (lg_x3.hip); wrs: lin_rs.h layout; pc / braw: ffn_chain.h packing and the unpadded bias
 struct LgBlockW { LgLinear a, b, c, ffn0, ffn3; float* ln_g = nullptr; float* ln_b = nullptr; };  // self: a=Wqkv,b=out_proj; cross: a=to_qk,b=to_v,c=to_out
 struct LgWeights {
   bool ready = false;
@@ -47,6 +47,7 @@ struct LgContext {
   hipEvent_t lnev[2 * LG_LINEARS] = {};   // around every linear_fm launch of a forward pass
   bool aev_ready = false;
   float attn_ms = 0.0f, lin_ms = 0.0f;
+  int lin_launches = 0;                   // linear-layer launches (or FFN-chain launches) of the last profiled forward pass
   double attn_flops = 0.0, attn_flops_alg = 0.0, lin_flops = 0.0;
 };
 
@@ -80,7 +81,9 @@ int lg_upload(dani_engine* e, const std::vector<float>& v, float** out) {
 }
 
 // pack a Linear ([out, in] row-major + bias) for linear_fm_kernel
-int lg_pack_raw(dani_engine* e, const std::vector<float>& w, const std::vector<float>& b, int out, int in, LgLinear* L) {
+// chain_role: how ffn_chain_kernel consumes this matrix (ffn_chain.h) -- 1: stage A, B operand from memory (natural k order);
+// 2: stage C, B operand = the previous stage's accumulators; 3: stage D, the same per 256-output pass
+int lg_pack_raw(dani_engine* e, const std::vector<float>& w, const std::vector<float>& b, int out, int in, LgLinear* L, int chain_role) {
   const int tiles = (out + 63) / 64;
   std::vector<float> wp((size_t)tiles * 64 * in), bp((size_t)tiles * 64);
   pack_conv_weights(w.data(), b.data(), in, out, 1, 32, 64, wp.data(), bp.data());
@@ -92,6 +95,12 @@ int lg_pack_raw(dani_engine* e, const std::vector<float>& w, const std::vector<f
     std::vector<float> wr((size_t)out * in);
     pack_linear_rs_host(w.data(), out, in, wr.data());
     if ((rc = lg_upload(e, wr, &L->wrs))) return rc;
+  }
+  if (chain_role && out % 256 == 0 && in % 16 == 0) {   // operand layout of the register-resident FFN chain
+    std::vector<float> pc((size_t)out * in);
+    pack_chain_weights_host(w.data(), out, in, chain_role, pc.data());
+    if ((rc = lg_upload(e, pc, &L->pc))) return rc;
+    if ((rc = lg_upload(e, b, &L->braw))) return rc;
   }
   // the same weight split into three bf16 terms, for the DANI_LG_GEMM_BF16X3 option
   std::vector<uint16_t> w3(x3_packed_u16(out, in));
@@ -111,7 +120,7 @@ int lg_get_linear(dani_engine* e, const std::string& name, int out, int in, std:
   return 0;
 }
 
-int lg_pack_linear(dani_engine* e, const std::string& name, int out, int in, LgLinear* L, const std::vector<int>* perm = nullptr) {
+int lg_pack_linear(dani_engine* e, const std::string& name, int out, int in, LgLinear* L, int chain_role, const std::vector<int>* perm = nullptr) {
   std::vector<float> w, b;
   int rc = lg_get_linear(e, name, out, in, w, b);
   if (rc) return rc;
@@ -123,7 +132,7 @@ int lg_pack_linear(dani_engine* e, const std::string& name, int out, int in, LgL
     }
     w.swap(w2); b.swap(b2);
   }
-  return lg_pack_raw(e, w, b, out, in, L);
+  return lg_pack_raw(e, w, b, out, in, L, chain_role);
 }
 
 // ffn.0 applied to cat[x, P(ctx)] with P an affine map (out_proj / to_out) folded in:
@@ -146,7 +155,7 @@ int lg_pack_ffn0_folded(dani_engine* e, const std::string& ffn0, const std::stri
     for (int m = 0; m < 256; m++) bb += (double)w0b[m] * (double)bp[m];
     b[o] = (float)bb;
   }
-  return lg_pack_raw(e, w, b, 512, 512, L);
+  return lg_pack_raw(e, w, b, 512, 512, L, 1);
 }
 
 // to_qk (pre-scaled by 64^-1/4, the factor the public CrossBlock applies to both sides) and to_v as one 512-row GEMM
@@ -161,7 +170,7 @@ int lg_pack_qkv_cross(dani_engine* e, const std::string& pc, LgLinear* L) {
   for (int i = 0; i < 256; i++) b[i] = bq[i] * sc;
   memcpy(&w[(size_t)256 * 256], wv.data(), wv.size() * 4);
   memcpy(&b[256], bv.data(), 256 * 4);
-  return lg_pack_raw(e, w, b, 512, 256, L);
+  return lg_pack_raw(e, w, b, 512, 256, L, 3);
 }
 
 int lg_vec(dani_engine* e, const std::string& name, size_t n, float** out) {
@@ -184,19 +193,19 @@ int lg_finalize(dani_engine* e) {
   for (int i = 0; i < LG_LAYERS; i++) {
     const std::string ps = "transformers." + std::to_string(i) + ".self_attn", pc = "transformers." + std::to_string(i) + ".cross_attn";
     LgBlockW& S = W->self_[i]; LgBlockW& C = W->cross_[i];
-    if ((rc = lg_pack_linear(e, ps + ".Wqkv", 768, 256, &S.a, &perm))) return rc;
+    if ((rc = lg_pack_linear(e, ps + ".Wqkv", 768, 256, &S.a, 3, &perm))) return rc;
     if ((rc = lg_pack_ffn0_folded(e, ps + ".ffn.0", ps + ".out_proj", &S.ffn0))) return rc;
     if ((rc = lg_vec(e, ps + ".ffn.1.weight", 512, &S.ln_g))) return rc;
     if ((rc = lg_vec(e, ps + ".ffn.1.bias", 512, &S.ln_b))) return rc;
-    if ((rc = lg_pack_linear(e, ps + ".ffn.3", 256, 512, &S.ffn3))) return rc;
+    if ((rc = lg_pack_linear(e, ps + ".ffn.3", 256, 512, &S.ffn3, 2))) return rc;
     if ((rc = lg_pack_qkv_cross(e, pc, &C.a))) return rc;
     if ((rc = lg_pack_ffn0_folded(e, pc + ".ffn.0", pc + ".to_out", &C.ffn0))) return rc;
     if ((rc = lg_vec(e, pc + ".ffn.1.weight", 512, &C.ln_g))) return rc;
     if ((rc = lg_vec(e, pc + ".ffn.1.bias", 512, &C.ln_b))) return rc;
-    if ((rc = lg_pack_linear(e, pc + ".ffn.3", 256, 512, &C.ffn3))) return rc;
+    if ((rc = lg_pack_linear(e, pc + ".ffn.3", 256, 512, &C.ffn3, 2))) return rc;
   }
   const std::string pa = "log_assignment." + std::to_string(LG_LAYERS - 1);
-  if ((rc = lg_pack_linear(e, pa + ".final_proj", 256, 256, &W->final_proj))) return rc;
+  if ((rc = lg_pack_linear(e, pa + ".final_proj", 256, 256, &W->final_proj, 3))) return rc;
   if ((rc = lg_vec(e, pa + ".matchability.weight", 256, &W->match_w))) return rc;
   auto mb = e->tensors.find(pa + ".matchability.bias");
   if (mb == e->tensors.end() || mb->second.size() != 1) return fail(e, DANI_ERR_WEIGHTS, "missing %s.matchability.bias", pa.c_str());
@@ -253,7 +262,7 @@ int lg_ensure(dani_engine* e, Context* c, LgContext** out, int pairs, int kmax) 
 }
 
 // the 9-layer forward + assignment statistics on stream s; the sets in L->d_sets point at their token-major inputs
-struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T; };   // T = all main regions + the tail region
+struct LgShape { int nsets, max_n, max_mp, max_span, max_tail, T, T_main; };   // T = all main regions (T_main) + the tail region
 
 // false: a linear layer refused its shape (nothing of that layer was launched)
 bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t s, bool prof, int gemm) {
@@ -278,22 +287,56 @@ bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
     else ok = launch_linear_fm(x0, K0, x1, K1, l.w, l.b, y, l.out, T, ld, res, L->cosb, L->sinb, rot, alpha, s, l.wrs) && ok;
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
   };
+  // The token-local chain between two attention launches -- ffn.0 -> LayerNorm + GELU -> ffn.3 (+ residual) -> the NEXT block's
+  // projection -- as ONE register-resident launch per block (ffn_chain.h) where its 16-token blocks fill the chip in whole rounds of
+  // 1024 waves (one per SIMD): the bench's 8 pairs are 16 384 main tokens = exactly one round.  The tokens behind them (the shared
+  // tail region, 32-64 tokens) keep the four small launches when they would cost the chain an extra round.
+  const int nb_all = T / 16, nb_main = sh.T_main / 16;
+  int chain_blocks = 0;
+  {
+    static const int env_chain = getenv("DANI_FFN_CHAIN") ? atoi(getenv("DANI_FFN_CHAIN")) : -1;
+    const int force = g_ffn_chain.load(std::memory_order_relaxed) >= 0 ? g_ffn_chain.load(std::memory_order_relaxed) : env_chain;
+    const bool have = W->self_[0].ffn0.pc && W->self_[0].ffn3.pc && W->cross_[0].a.pc && W->self_[0].a.pc && W->final_proj.pc;
+    auto rounds = [](int nb) { return (nb + 1023) / 1024; };
+    // cost in units of one round of the chain (~145 us) against the four launches at their measured rate (~172 us per 16 416 tokens)
+    const bool pays = nb_main >= 768 && rounds(nb_main) * 145.0 < (double)T / 16416.0 * 172.0;
+    if (gemm == DANI_LG_GEMM_F32 && have && force != 0 && (force == 1 || pays))
+      chain_blocks = rounds(nb_all) == rounds(nb_main) ? nb_all : nb_main;
+  }
+  const int T_rest = T - 16 * chain_blocks;                 // tokens of the tail region that keep the four-launch path
+  // one FFN block + the projection that follows it; `next` = nullptr: none (never happens: the last block feeds final_proj)
+  auto ffn_and_next = [&](const LgBlockW& Bk, const LgLinear& next, float* y, int rot, float alpha) {
+    if (chain_blocks > 0) {
+      if (prof) (void)hipEventRecord(L->lnev[li++], s);
+      ok = launch_ffn_chain_fm(L->x, L->ctx, Bk.ffn0.pc, Bk.ffn0.braw, Bk.ln_g, Bk.ln_b, Bk.ffn3.pc, Bk.ffn3.braw, next.pc, next.braw, next.out, y,
+                               L->cosb, L->sinb, rot, alpha, chain_blocks, ld, s) && ok;
+      if (T_rest > 0) {
+        const size_t o = (size_t)16 * chain_blocks;
+        ok = launch_linear_fm(L->x + o, 256, L->ctx + o, 256, Bk.ffn0.w, Bk.ffn0.b, L->hbuf + o, 512, T_rest, ld, nullptr, nullptr, nullptr, 0, 1.0f, s, Bk.ffn0.wrs) && ok;
+        launch_ln_gelu(L->hbuf + o, Bk.ln_g, Bk.ln_b, T_rest, ld, s);
+        ok = launch_linear_fm(L->hbuf + o, 512, nullptr, 0, Bk.ffn3.w, Bk.ffn3.b, L->x + o, 256, T_rest, ld, L->x + o, nullptr, nullptr, 0, 1.0f, s, Bk.ffn3.wrs) && ok;
+        ok = launch_linear_fm(L->x + o, 256, nullptr, 0, next.w, next.b, y + o, next.out, T_rest, ld, nullptr, L->cosb + o, L->sinb + o, rot, alpha, s, next.wrs) && ok;
+      }
+      if (prof) (void)hipEventRecord(L->lnev[li++], s);
+      return;
+    }
+    lin(Bk.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
+    launch_ln_gelu(L->hbuf, Bk.ln_g, Bk.ln_b, T, ld, s);
+    lin(Bk.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
+    lin(next, L->x, 256, nullptr, 0, y, nullptr, rot, alpha);
+  };
+  // self block: Wqkv (+rotary) -> attention -> [out_proj folded into] ffn.0 -> LN+GELU -> ffn.3 + residual;
+  // cross block: [to_qk*s | to_v] in one GEMM -> attention over the partner set -> [to_out folded into] ffn.0 ...
+  lin(W->self_[0].a, L->x, 256, nullptr, 0, L->qkv, nullptr, 512, 1.0f);
   for (int i = 0; i < LG_LAYERS; i++) {
     const LgBlockW& S = W->self_[i]; const LgBlockW& C = W->cross_[i];
-    // self block: Wqkv (+rotary) -> attention -> [out_proj folded into] ffn.0 -> LN+GELU -> ffn.3 + residual
-    lin(S.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 512, 1.0f);
     attn(L->qkv, L->qkv + (size_t)256 * ld, L->qkv + (size_t)512 * ld, 0, 0.125f);
-    lin(S.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
-    launch_ln_gelu(L->hbuf, S.ln_g, S.ln_b, T, ld, s);
-    lin(S.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
-    // cross block: [to_qk*s | to_v] in one GEMM -> attention over the partner set -> [to_out folded into] ffn.0 ...
-    lin(C.a, L->x, 256, nullptr, 0, L->qkv, nullptr, 0, 1.0f);
+    ffn_and_next(S, C.a, L->qkv, 0, 1.0f);
     attn(L->qkv, L->qkv, L->qkv + (size_t)256 * ld, 1, 1.0f);
-    lin(C.ffn0, L->x, 256, L->ctx, 256, L->hbuf, nullptr, 0, 1.0f);
-    launch_ln_gelu(L->hbuf, C.ln_g, C.ln_b, T, ld, s);
-    lin(C.ffn3, L->hbuf, 512, nullptr, 0, L->x, L->x, 0, 1.0f);
+    if (i + 1 < LG_LAYERS) ffn_and_next(C, W->self_[i + 1].a, L->qkv, 512, 1.0f);
+    else ffn_and_next(C, W->final_proj, L->md, 0, 0.25f);   // / d^0.25, d = 256
   }
-  lin(W->final_proj, L->x, 256, nullptr, 0, L->md, nullptr, 0, 0.25f);   // / d^0.25, d = 256
+  L->lin_launches = li / 2;
   launch_matchability(L->x, W->match_w, W->match_b, L->logsig, T, ld, s);
   const size_t pstride = (size_t)(round_up(L->kmax, 32) + 64) * L->sim_ld;
   launch_lg_densify(L->md, L->logsig, L->d_sets, nsets, max_n, L->md_dense, L->logsig_dense, ld, s);
@@ -319,6 +362,7 @@ extern "C" {
 int dani_lg_set_kernel_option(const char* name, int32_t value) {
   if (!name) return DANI_ERR_INVALID;
   if (!strcmp(name, "lin_rs")) { if (value < -1 || value > 4) return DANI_ERR_INVALID; dani::g_lin_force_rs = value; return DANI_OK; }
+  if (!strcmp(name, "ffn_chain")) { if (value < -1 || value > 1) return DANI_ERR_INVALID; dani::g_ffn_chain = value; return DANI_OK; }
   if (!strcmp(name, "attn")) {   // the documented kernels only: 1 / 3 / 4 / 5 (attn_ks, the bf16x3 forms on the f32 path, attn_k4 at any size) stay probe-only
     if (value != 0 && value != 2 && value != 6 && value != 7 && value != 8) return DANI_ERR_INVALID;
     dani::g_attn_force = value; return DANI_OK;
@@ -364,7 +408,7 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
   // token layout (common.h, LgSet): set 2p = side 0 of pair p, set 2p+1 = side 1.  Main regions first, each padded to a
   // multiple of 32 tokens; then the shared tail region; the dense layout of the assignment stage pads every set to 32.
   int off = 0, doff = 0, ntail = 0, max_n = 0;
-  LgShape sh{2 * P, 0, 0, 0, 0, 0};
+  LgShape sh{2 * P, 0, 0, 0, 0, 0, 0};
   L->last_sets.assign(2 * P, LgSet());
   auto place = [&](LgSet& a, int n) {
     const int t = n % 32;
@@ -386,7 +430,7 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
     b.partner_off = a.tok_off; b.partner_n = a.n; b.partner_nmain = a.nmain; b.partner_tail_off = a.tail_off;
   }
   const int T = T_main + round_up(ntail, 32);
-  sh.max_n = max_n; sh.T = T;
+  sh.max_n = max_n; sh.T = T; sh.T_main = T_main;
   // sizes: explicit (w,h) or 1 + max - min of the keypoints (needs host keypoints)
   std::vector<float> hk;
   auto host_kpts = [&](const float* k, int p, int n) -> const float* {
@@ -458,7 +502,7 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
     }
     L->attn_flops = fl; L->attn_flops_alg = fla;
     tot = 0.0f;
-    for (int i = 0; i < 2 * LG_LINEARS; i += 2) { float m = 0.0f; (void)hipEventElapsedTime(&m, L->lnev[i], L->lnev[i + 1]); tot += m; }
+    for (int i = 0; i < 2 * L->lin_launches && i < 2 * LG_LINEARS; i += 2) { float m = 0.0f; (void)hipEventElapsedTime(&m, L->lnev[i], L->lnev[i + 1]); tot += m; }
     L->lin_ms = tot;
     double ntok = 0.0;   // algorithmic: valid tokens only; per token 2 * out * in flop per layer
     for (const LgSet& st : L->last_sets) ntok += st.n;
@@ -604,7 +648,7 @@ int dani_lg_linear_profile(dani_engine* e, float* total_ms, double* total_flop, 
   if (!e || !L) return DANI_ERR_INVALID;
   if (total_ms) *total_ms = L->lin_ms;
   if (total_flop) *total_flop = L->lin_flops;
-  if (launches) *launches = LG_LINEARS;
+  if (launches) *launches = L->lin_launches;   // 55 linear launches, or 1 + 18 with the FFN chain (each chain counted once, its tail-region launches included)
   return DANI_OK;
 }
 

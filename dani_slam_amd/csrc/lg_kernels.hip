@@ -1415,8 +1415,23 @@ __global__ __launch_bounds__(256, 2) void attn_x3w_kernel(const float* Q, const 
 
 }  // namespace dani
 #include "attn_rs.h"
+#include "ffn_chain.h"
 namespace dani {
 
+bool launch_ffn_chain_fm(float* x, const float* ctx, const float* p0, const float* b0, const float* gamma, const float* beta,
+                         const float* p3, const float* b3, const float* pd, const float* bd, int OUTD, float* y, const float* cosb,
+                         const float* sinb, int rot_rows, float alpha, int nblocks, int ld, hipStream_t s) {
+  FfnChainArgs a;
+  a.x = x; a.ctx = ctx; a.p0 = p0; a.b0 = b0; a.gamma = gamma; a.beta = beta; a.p3 = p3; a.b3 = b3; a.pd = pd; a.bd = bd;
+  a.y = y; a.cosb = cosb; a.sinb = sinb; a.OUTD = OUTD; a.rot_rows = rot_rows; a.alpha = alpha; a.ld = ld; a.nblocks = nblocks;
+  return launch_ffn_chain(a, s);
+}
+void pack_chain_weights_host(const float* w, int out, int in, int role, float* dst) {
+  if (role == 3) pack_chain_proj(w, out, in, dst);
+  else pack_chain_a(w, out, in, role == 2, dst);
+}
+
+std::atomic<int> g_ffn_chain{-1};   // dani_lg_set_kernel_option("ffn_chain"): -1 = per shape (lg_forward), 0 = never, 1 = always
 std::atomic<int> g_attn_force{0};   // tuning hook of tools/probes/attn_bench.hip: 1 = attn_ks_kernel, 2 = attn_kernel<4>, 3 = attn_x3_kernel, 4 = attn_x3w_kernel, 5 = attn_k4_kernel, 6 = attn_rs_kernel
 
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,

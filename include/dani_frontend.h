@@ -159,6 +159,8 @@ DANI_API int dani_lg_set_gemm(dani_engine* e, int32_t mode);
  *   "lin_rs"    -1 = per shape (default), 0 = LDS-tiled linear_fm_kernel only, 1..3 = linear_rs_kernel with that tile,
  *                4 = every token through linear_rs_kernel's K-split 32 x 32 blocks (the form its tail tokens take)
  *   "attn"       0 = per shape (default), 2 = LDS-tiled attn_kernel<4>, 6 / 7 / 8 = attn_rs_kernel with a ring of 8 / 4 / 16 loads
+ *   "ffn_chain" -1 = per shape (default), 0 = never, 1 = always: ffn.0 -> LayerNorm + GELU -> ffn.3 -> next projection as ONE
+ *                register-resident launch per block (ffn_chain_kernel) instead of four
  * Returns DANI_ERR_INVALID for an unknown name or any other value (the probe-only kernels are not selectable here). */
 DANI_API int dani_lg_set_kernel_option(const char* name, int32_t value);
 /* How the calling thread waits for the GPU inside every entry point, process-wide: 0 = block in hipStreamSynchronize (default:

@@ -120,12 +120,12 @@ def test_process_wide_options_validate_their_arguments():
     lib.dani_set_host_wait.argtypes = [ctypes.c_int32]
     assert lib.dani_lg_set_kernel_option(None, 0) == frontend.DANI_ERR_INVALID
     assert lib.dani_lg_set_kernel_option(b"no_such_option", 0) == frontend.DANI_ERR_INVALID
-    for name, good, bad in ((b"lin_rs", (-1, 0, 1, 2, 3, 4), (-2, 5)), (b"attn", (0, 2, 6, 7, 8), (-1, 1, 3, 4, 5, 9))):
+    for name, good, bad in ((b"lin_rs", (-1, 0, 1, 2, 3, 4), (-2, 5)), (b"attn", (0, 2, 6, 7, 8), (-1, 1, 3, 4, 5, 9)), (b"ffn_chain", (-1, 0, 1), (-2, 2))):
         for v in bad:
             assert lib.dani_lg_set_kernel_option(name, v) == frontend.DANI_ERR_INVALID, (name, v)
         for v in good:
             assert lib.dani_lg_set_kernel_option(name, v) == 0, (name, v)
-    assert lib.dani_lg_set_kernel_option(b"lin_rs", -1) == 0 and lib.dani_lg_set_kernel_option(b"attn", 0) == 0   # the defaults
+    assert lib.dani_lg_set_kernel_option(b"lin_rs", -1) == 0 and lib.dani_lg_set_kernel_option(b"attn", 0) == 0 and lib.dani_lg_set_kernel_option(b"ffn_chain", -1) == 0   # the defaults
     assert lib.dani_set_host_wait(7) == frontend.DANI_ERR_INVALID
     assert lib.dani_set_host_wait(1) == 0 and lib.dani_set_host_wait(0) == 0
 

@@ -347,3 +347,52 @@ def test_non_finite_inputs_do_not_poison_later_calls(lg_weights, sp_weights):
     for (m0, s0), (m1, s1) in zip(before, after):
         assert np.array_equal(m0, m1) and np.array_equal(s0, s1)
     e.close()
+
+
+def test_ffn_chain_matches_the_four_launch_path(lg_weights, sp_weights):
+    """Round 4: ffn.0 -> LayerNorm + GELU -> ffn.3 (+ residual) -> the next block's projection as ONE register-resident launch per
+    block (csrc/ffn_chain.h, 16 tokens per wavefront through v_mfma_f32_16x16x4_f32, accumulators reused as B operands) against
+    the four launches it replaces, in one process (dani_lg_set_kernel_option "ffn_chain").  Same function, other summation
+    orders: <= 2 near-tie match flips per pair, scores within 1e-4; and against the oracle itself on two pairs."""
+    from dani_slam_amd import frontend
+    w = dict(sp_weights); w.update(lg_weights)
+    e = frontend.Engine(device=0, weights=w, max_batch=8)
+
+    def batch(sz, seed):
+        prs = [synth.matching_pair(seed + i, n0=a, n1=b) for i, (a, b) in enumerate(sz)]
+        cap = max(1032, max(max(a, b) for a, b in sz) + 2)
+        K0 = np.zeros((len(sz), cap, 2), np.float32); D0 = np.zeros((len(sz), cap, 256), np.float32)
+        K1 = np.zeros((len(sz), cap, 2), np.float32); D1 = np.zeros((len(sz), cap, 256), np.float32)
+        for p, (k0, d0, k1, d1, _) in enumerate(prs):
+            K0[p, :len(k0)] = k0; D0[p, :len(k0)] = d0; K1[p, :len(k1)] = k1; D1[p, :len(k1)] = d1
+        return prs, (K0, D0, [a for a, _ in sz], K1, D1, [b for _, b in sz])
+    # (a) the bench's shape: 16 sets of 1024-1027 keypoints = 16 384 main tokens (1024 blocks: one round) + a tail region that
+    #     keeps the four small launches; (b) no tail region at all; (c) forced onto a small ragged batch (any block count works)
+    shapes = {"bench": [(1025, 1025), (1026, 1024), (1024, 1025), (1025, 1026), (1027, 1025), (1025, 1024), (1024, 1024), (1026, 1025)],
+              "no_tail": [(1024, 1024)] * 8, "small": [(700, 1280), (1025, 333)]}
+    try:
+        for name, sz in shapes.items():
+            pairs, args = batch(sz, 300)
+            res = {}
+            for mode in (0, 1, -1):
+                e.lg_set_kernel_option("ffn_chain", mode)
+                res[mode] = e.lg_match_batch(*args, SIZE, SIZE, 0.05)
+            assert min(len(m) for m, _ in res[0]) > 100, name
+            for mode in (1, -1):
+                for p in range(len(sz)):
+                    a = {tuple(x): v for x, v in zip(res[0][p][0].tolist(), res[0][p][1])}
+                    b = {tuple(x): v for x, v in zip(res[mode][p][0].tolist(), res[mode][p][1])}
+                    common = set(a) & set(b)
+                    assert len(common) >= max(len(a), len(b)) - 2, (name, mode, p, len(a), len(b))
+                    assert max(abs(a[c] - b[c]) for c in common) < 1e-4, (name, mode, p)
+            if name == "bench":
+                for p in (0, 4):
+                    k0, d0, k1, d1, _ = pairs[p]
+                    mo, so = lg.match_descriptors(lg_weights, k0, d0, k1, d1, SIZE, SIZE, 0.05)
+                    want = {tuple(x): float(v) for x, v in zip(mo.tolist(), so)}
+                    got = {tuple(x): float(v) for x, v in zip(res[1][p][0].tolist(), res[1][p][1])}
+                    assert len(set(got) ^ set(want)) <= max(2, len(want) // 100), (p, len(got), len(want))
+                    assert max(abs(got[k] - want[k]) for k in set(got) & set(want)) < 1e-3, p
+    finally:
+        e.lg_set_kernel_option("ffn_chain", -1)
+        e.close()
