@@ -216,6 +216,7 @@ void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, i
 bool launch_ffn_chain_fm(float* x, const float* ctx, const float* p0, const float* b0, const float* gamma, const float* beta,
                          const float* p3, const float* b3, const float* pd, const float* bd, int OUTD, float* y, const float* cosb,
                          const float* sinb, int rot_rows, float alpha, int nblocks, int ld, hipStream_t s);
+constexpr int LG_CHAIN_SLACK_FLOATS = 16 * 256;   // zero floats behind every chain-packed matrix (= ffn_chain.h FC_SLACK_FLOATS)
 void pack_chain_weights_host(const float* w_row_major, int out, int in, int role, float* dst);   // role 1 / 2 / 3, see lg_engine.cpp lg_pack_raw
 void launch_posenc(const LgSet* sets, int nsets, int max_span, const float* wr, float* cosb, float* sinb, int ld, hipStream_t s);
 void launch_desc_to_fm(const LgSet* sets, int nsets, int max_span, float* x, int ld, hipStream_t s);

@@ -97,7 +97,7 @@ int lg_pack_raw(dani_engine* e, const std::vector<float>& w, const std::vector<f
     if ((rc = lg_upload(e, wr, &L->wrs))) return rc;
   }
   if (chain_role && out % 256 == 0 && in % 16 == 0) {   // operand layout of the register-resident FFN chain
-    std::vector<float> pc((size_t)out * in);
+    std::vector<float> pc((size_t)out * in + LG_CHAIN_SLACK_FLOATS, 0.0f);   // the kernel's last refills read into the slack
     pack_chain_weights_host(w.data(), out, in, chain_role, pc.data());
     if ((rc = lg_upload(e, pc, &L->pc))) return rc;
     if ((rc = lg_upload(e, b, &L->braw))) return rc;

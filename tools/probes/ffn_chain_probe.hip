@@ -29,7 +29,7 @@ static int make_lin(Lin& L, int out, int in, unsigned seed, float gain, bool acc
   std::vector<float> w((size_t)out * in), b(out);
   CK(hipMemcpy(w.data(), L.w, w.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), L.b, b.size() * 4, hipMemcpyDeviceToHost));
   const int tiles = (out + 63) / 64;
-  std::vector<float> wp((size_t)tiles * 64 * in), bp((size_t)tiles * 64), wrs((size_t)out * in), pc((size_t)out * in);
+  std::vector<float> wp((size_t)tiles * 64 * in), bp((size_t)tiles * 64), wrs((size_t)out * in), pc((size_t)out * in + LG_CHAIN_SLACK_FLOATS, 0.0f);
   pack_conv_weights(w.data(), b.data(), in, out, 1, 32, 64, wp.data(), bp.data());
   pack_linear_rs_host(w.data(), out, in, wrs.data());
   if (proj) pack_chain_proj(w.data(), out, in, pc.data()); else pack_chain_a(w.data(), out, in, acc_order, pc.data());
