@@ -288,9 +288,11 @@ bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
     if (prof) (void)hipEventRecord(L->lnev[li++], s);
   };
   // The token-local chain between two attention launches -- ffn.0 -> LayerNorm + GELU -> ffn.3 (+ residual) -> the NEXT block's
-  // projection -- as ONE register-resident launch per block (ffn_chain.h) where its 16-token blocks fill the chip in whole rounds of
-  // 1024 waves (one per SIMD): the bench's 8 pairs are 16 384 main tokens = exactly one round.  The tokens behind them (the shared
-  // tail region, 32-64 tokens) keep the four small launches when they would cost the chain an extra round.
+  // projection -- as ONE register-resident launch per block (ffn_chain.h) where that pays.  Measured on MI355X (tools/probes/
+  // ffn_chain_probe.hip, profiles/r04_ffn_chain_probe.txt): one round of 1024 blocks (one wave per SIMD) takes ~160 us against ~181 us
+  // for the four launches over the same 16 k tokens -- but the tokens behind the whole rounds (the shared tail region, 32-64 columns)
+  // keep the four small launches, ~33 us in the pipeline, so ONE round (the default bench's 8 pairs) does not pay (10.99 against
+  // 10.72 ms per step, profiles/r04_null_results.md) and several do: 64 frames per call = 8 rounds.
   const int nb_all = T / 16, nb_main = sh.T_main / 16;
   int chain_blocks = 0;
   {
@@ -298,10 +300,10 @@ bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
     const int force = g_ffn_chain.load(std::memory_order_relaxed) >= 0 ? g_ffn_chain.load(std::memory_order_relaxed) : env_chain;
     const bool have = W->self_[0].ffn0.pc && W->self_[0].ffn3.pc && W->cross_[0].a.pc && W->self_[0].a.pc && W->final_proj.pc;
     auto rounds = [](int nb) { return (nb + 1023) / 1024; };
-    // cost in units of one round of the chain (~145 us) against the four launches at their measured rate (~172 us per 16 416 tokens)
-    const bool pays = nb_main >= 768 && rounds(nb_main) * 145.0 < (double)T / 16416.0 * 172.0;
-    if (gemm == DANI_LG_GEMM_F32 && have && force != 0 && (force == 1 || pays))
-      chain_blocks = rounds(nb_all) == rounds(nb_main) ? nb_all : nb_main;
+    const bool all_in = rounds(nb_all) == rounds(nb_main);      // the tail region fits the last round: no launches of its own
+    const double chain_us = rounds(all_in ? nb_all : nb_main) * 160.0 + (all_in ? 0.0 : 33.0), four_us = (double)T / 16416.0 * 181.0;
+    const bool pays = nb_main >= 768 && chain_us < four_us - 5.0;
+    if (gemm == DANI_LG_GEMM_F32 && have && force != 0 && (force == 1 || pays)) chain_blocks = all_in ? nb_all : nb_main;
   }
   const int T_rest = T - 16 * chain_blocks;                 // tokens of the tail region that keep the four-launch path
   // one FFN block + the projection that follows it; `next` = nullptr: none (never happens: the last block feeds final_proj)

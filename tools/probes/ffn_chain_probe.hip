@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <vector>
 using namespace dani;
+#ifndef NT_BLOCKS
+#define NT_BLOCKS 0   // the last NT_BLOCKS 16-token blocks are left out (the shadow experiment gave them to the first workgroups: tools/probes/ffn_chain_shadow_null.h.txt)
+#endif
 
 __global__ void fill_rand(float* p, size_t n, unsigned seed, float scale, float shift) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -94,7 +97,7 @@ int main(int argc, char** argv) {
       auto one = [&]() {
         FfnChainArgs a;
         a.x = X; a.ctx = CTX; a.p0 = f0.pc; a.b0 = f0.b; a.gamma = G; a.beta = Be; a.p3 = f3.pc; a.b3 = f3.b; a.pd = pd.pc; a.bd = pd.b;
-        a.y = Y; a.cosb = COS; a.sinb = SIN; a.OUTD = pd.out; a.rot_rows = rot; a.alpha = alpha; a.ld = ld; a.nblocks = T / 16;
+        a.y = Y; a.cosb = COS; a.sinb = SIN; a.OUTD = pd.out; a.rot_rows = rot; a.alpha = alpha; a.ld = ld; a.nblocks = T / 16 - NT_BLOCKS;
         return launch_ffn_chain(a, 0);
       };
       reset(); if (!four()) { printf("linear refused\n"); return 1; }
@@ -106,9 +109,17 @@ int main(int argc, char** argv) {
       std::vector<float> a((size_t)256 * ld), b((size_t)256 * ld), c((size_t)768 * ld), d((size_t)768 * ld);
       CK(hipMemcpy(a.data(), XR, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), X, b.size() * 4, hipMemcpyDeviceToHost));
       CK(hipMemcpy(c.data(), YR, c.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(d.data(), Y, d.size() * 4, hipMemcpyDeviceToHost));
-      double mx = 0, my = 0, sx = 0, sy = 0;
-      for (int r = 0; r < 256; r++) for (int t = 0; t < T; t++) { mx = std::max(mx, (double)fabs(a[(size_t)r * ld + t] - b[(size_t)r * ld + t])); sx += fabs(a[(size_t)r * ld + t]); }
-      for (int r = 0; r < pd.out; r++) for (int t = 0; t < T; t++) { my = std::max(my, (double)fabs(c[(size_t)r * ld + t] - d[(size_t)r * ld + t])); sy += fabs(c[(size_t)r * ld + t]); }
+      double mx = 0, my = 0, sx = 0, sy = 0, mxt = 0, myt = 0;
+      const int Tm = T - 16 * NT_BLOCKS;     // columns >= Tm are shadow tokens
+      for (int r = 0; r < 256; r++) for (int t = 0; t < T; t++) { const double e = fabs(a[(size_t)r * ld + t] - b[(size_t)r * ld + t]); if (t < Tm) mx = std::max(mx, e); else mxt = std::max(mxt, e); sx += fabs(a[(size_t)r * ld + t]); }
+      for (int r = 0; r < pd.out; r++) for (int t = 0; t < T; t++) { const double e = fabs(c[(size_t)r * ld + t] - d[(size_t)r * ld + t]); if (t < Tm) my = std::max(my, e); else myt = std::max(myt, e); sy += fabs(c[(size_t)r * ld + t]); }
+      if (NT_BLOCKS) {
+        printf("   shadow columns: max |dx'| %.3g  max |dy| %.3g;  x' col %d rows 0..5 ref/got:", mxt, myt, Tm);
+        for (int r = 0; r < 6; r++) printf(" %.4f/%.4f", a[(size_t)r * ld + Tm], b[(size_t)r * ld + Tm]);
+        printf("\n   y col %d rows 0..5 ref/got:", Tm);
+        for (int r = 0; r < 6; r++) printf(" %.4f/%.4f", c[(size_t)r * ld + Tm], d[(size_t)r * ld + Tm]);
+        printf("\n");
+      }
       printf("T=%d proj %d (rot %d): chain vs four launches: max |dx'| %.3g (mean |x'| %.3f)  max |dy| %.3g (mean |y| %.3f)\n", T, pd.out, rot, mx, sx / (256.0 * T), my, sy / ((double)pd.out * T));
       for (int form = 0; form < 2; form++) {
         std::vector<double> us;
