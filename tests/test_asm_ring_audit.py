@@ -1,4 +1,4 @@
-"""CPU: static audit of the EMITTED code of the register-streaming kernels (lin_rs.h, attn_rs.h).
+"""CPU: static audit of the EMITTED code of the register-streaming kernels (lin_rs.h, attn_rs.h, ffn_chain.h).
 
 Their operand loads are inline asm whose completion hipcc does not track; the kernels order every use behind a hand-counted
 `s_waitcnt vmcnt(N)`.  A compiler upgrade or an edit that moves a use in front of its wait would give wrong operands on some
@@ -33,10 +33,22 @@ def _audit(path, *names):
 
 
 def test_every_use_of_an_asm_loaded_register_is_behind_a_covering_wait(asm):
-    r = _audit(asm, "linear_rs_kernel", "attn_rs_kernel")
+    r = _audit(asm, "linear_rs_kernel", "attn_rs_kernel", "ffn_chain_kernel")
     assert r.returncode == 0, r.stdout[-2000:]
     checked = [int(x) for x in re.findall(r"(\d+) scalar-base loads checked", r.stdout)]
-    assert len(checked) >= 5 and min(checked) >= 30, r.stdout      # three linear tiles, two attention ring depths
+    assert len(checked) >= 6 and min(checked) >= 30, r.stdout      # three linear tiles, two attention ring depths, the FFN chain
+    assert re.search(r"ffn_chain_kernel\w*: (\d+) scalar-base loads checked", r.stdout), r.stdout
+
+
+def test_the_audit_flags_a_weakened_wait_in_the_ffn_chain(asm, tmp_path):
+    s = open(asm).read()
+    m = re.search(r"\n(_ZN4dani16ffn_chain_kernel\w*):[^\n]*\n(.*?)\.end_amdhsa_kernel", s, re.S)
+    body = m.group(2)
+    assert "s_waitcnt vmcnt(15)" in body and "s_waitcnt vmcnt(17)" in body   # chain_pass16's ring of 16; stage A's 8 + 8 + B ring
+    bad = tmp_path / "bad_chain.s"
+    bad.write_text(s.replace(body, body.replace("s_waitcnt vmcnt(15)", "s_waitcnt vmcnt(40)").replace("s_waitcnt vmcnt(17)", "s_waitcnt vmcnt(40)")))
+    r = _audit(str(bad), "ffn_chain_kernel")
+    assert r.returncode == 1 and "first use before a covering wait" in r.stdout
 
 
 def test_the_audit_flags_a_weakened_wait(asm, tmp_path):

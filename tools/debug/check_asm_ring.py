@@ -31,21 +31,22 @@ def operands(line):
 
 def check(name, lines):
     # basic blocks; a block ending in a backward branch to its own label is a loop body: duplicate it
+    # (a block also ends BEHIND every branch: the straight-line code that follows a loop is not part of its body)
     labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"\.LBB\d+_\d+:", l)}
     seq = []
-    i = 0
-    starts = sorted(labels.values()) + [len(lines)]
+    cuts = set(labels.values()) | {i + 1 for i, l in enumerate(lines) if re.match(r"\s*s_c?branch", l)}
+    starts = sorted(c for c in cuts if 0 < c < len(lines)) + [len(lines)]
     for a, b in zip([0] + starts[:-1], starts):
         blk = lines[a:b]
         lab = lines[a].split(":")[0] if a in labels.values() else None
-        loop = lab and any(re.search(r"s_cbranch\w*\s+" + re.escape(lab) + r"\b", l) for l in blk)
+        loop = lab and re.search(r"s_cbranch\w*\s+" + re.escape(lab) + r"\b", blk[-1])
         seq += blk + (blk if loop else [])
     bad = 0
     nloads = 0
     is_vmem = lambda t: t.startswith(("global_", "buffer_", "scratch_", "flat_"))
     for i, l in enumerate(seq):
         t = l.strip()
-        m = re.match(r"global_load_dwordx[24]\s+(v\[\d+:\d+\]),\s*v\d+,\s*s\[\d+:\d+\]", t)
+        m = re.match(r"global_load_dword(?:x[24])?\s+(v\[\d+:\d+\]|v\d+),\s*v\d+,\s*s\[\d+:\d+\]", t)
         if not m:
             continue
         nloads += 1
