@@ -61,6 +61,9 @@ enum ConvVariant {
   CONV3_F20_SILU_K4 = 37, CONV3S2_F20_SILU_K2 = 38, CONV1_F20_SILU_K2 = 39,
   // SuperPoint's conv1b with conv1a computed inside the kernel from the u8 image (conv_mfma.hip, Cfg::F1A)
   CONV3_ROW32_RELU_POOL_F1A = 40, CONV3_ROW32N_RELU_POOL_F1A = 41,
+  // SuperPoint's heads with their post-processing in the epilogue (conv_mfma.hip, Cfg::EPI): convPb + softmax + depth-to-space
+  // (96 couts per workgroup), convDb + L2 norm + NHWC (256 couts per workgroup); 8 x 16 cells per workgroup
+  CONV1_BLK16S_SOFTMAX_D2S = 42, CONV1_BLK16S_L2NORM_NHWC = 43,
 };
 
 // Canonical K segmentation of a YOLOv5s convolution (conv_mfma.hip, Cfg::SEG; oracle/sp_oracle.cpp orc_conv2d_ex follows the
@@ -103,7 +106,7 @@ inline int conv_variant_cc(ConvVariant v) {
   return (v == CONV1_BLK16_LINEAR || v == CONV1_ROW32_SILU || v == CONV1_BLK16_SILU || v == CONV1_BLK16S_LINEAR ||
           v == CONV1_BLK16S_SILU || v == CONV1_ROW32N_SILU || v == CONV1_R4_SILU || v == CONV1_R4_LINEAR ||
           v == CONV1_BLK16S_SILU_K2 || v == CONV1_R4_SILU_K2 || v == CONV1_R4_LINEAR_K2 || v == CONV1_F40_SILU ||
-          v == CONV1_F40_LINEAR || v == CONV1_F20_SILU_K2) ? 32 : ((v == CONV6S2_ROW32_SILU || v == CONV6S2_ROW32N_SILU) ? 4 : 8);
+          v == CONV1_F40_LINEAR || v == CONV1_F20_SILU_K2 || v == CONV1_BLK16S_SOFTMAX_D2S || v == CONV1_BLK16S_L2NORM_NHWC) ? 32 : ((v == CONV6S2_ROW32_SILU || v == CONV6S2_ROW32N_SILU) ? 4 : 8);
 }
 inline int conv_variant_kseg(ConvVariant v) {
   switch (v) {
@@ -113,7 +116,11 @@ inline int conv_variant_kseg(ConvVariant v) {
     default: return 1;
   }
 }
-inline int conv_variant_nco(ConvVariant v) { return (v >= CONV3_BLK16S_RELU && v != CONV3_ROW32_RELU_POOL_F1A) ? 32 : 64; }   // couts per workgroup
+inline int conv_variant_nco(ConvVariant v) {   // couts per workgroup
+  if (v == CONV1_BLK16S_SOFTMAX_D2S) return 96;
+  if (v == CONV1_BLK16S_L2NORM_NHWC) return 256;
+  return (v >= CONV3_BLK16S_RELU && v != CONV3_ROW32_RELU_POOL_F1A) ? 32 : 64;
+}
 // the small-grid twin of a 16x16-tile variant (or the variant itself)
 inline ConvVariant conv_small_variant(ConvVariant v) {
   switch (v) {
@@ -136,6 +143,8 @@ bool launch_conv_mfma(const ConvLayerPlan& L, const ActDesc& in, const ActDesc& 
 bool launch_conv_mfma_f1a(const ConvLayerPlan& L, const uint8_t* img, int img_stride, size_t img_fs, const float* w1a, const float* b1a,
                           const ActDesc& in, const ActDesc& out, int B, hipStream_t s, int reserve_lds = 0);
 bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds = 0);
+// SuperPoint's heads finished in the epilogue (CONV1_BLK16S_SOFTMAX_D2S -> prob [B][8Hc][8Wc], CONV1_BLK16S_L2NORM_NHWC -> [B][Hc*Wc][256])
+bool launch_conv_head(const ConvLayerPlan& L, const ActDesc& in, float* dst, size_t dst_fs, int B, hipStream_t s, int reserve_lds = 0);
 const char* conv_kernel_name(ConvVariant v);
 
 // semi [B][65(+pad)][..] padded planar -> prob [B][PH][PW] dense

@@ -76,9 +76,20 @@ __device__ int g_conv_launches;
 // (TH + 4) x (TW + 4) u8 window of its tile in LDS and every thread forms the haloed conv1a values of the next 8-channel chunk on
 // the vector ALU -- 9 fmaf per value in conv1a_kernel's own order, so bit for bit what that kernel stores -- under the current
 // chunk's MFMAs.  Positions outside the image are conv1b's zero padding (NOT conv1a of a padded image).
-template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2, int SEG_ = 1, int FW_ = 0, bool F1A_ = false>
+// EPI_: SuperPoint's two heads finish inside their last 1 x 1 layer (a workgroup holds ALL output channels of its 128 cells):
+//   EPI_SOFTMAX_D2S  convPb (65 channels, NCB_ = 3): softmax over the channels, dustbin dropped, depth-to-space 8 x 8 into the dense
+//                    probability map (/root/reference/src/SuperPoint.cpp:82-93) -- softmax_d2s_kernel's arithmetic, value for value
+//   EPI_L2NORM_NHWC  convDb (256 channels, NCB_ = 8): desc / ||desc||_2 per cell, written as [cell][256] for the keypoint sampler
+//                    (:79-80) -- desc_norm_kernel's arithmetic
+// The raw layer outputs (semi, coarse descriptors) never reach HBM; sp_engine.cpp re-runs the plain layer for the debug hooks.
+enum { EPI_NONE = 0, EPI_SOFTMAX_D2S = 1, EPI_L2NORM_NHWC = 2 };
+template <int KS_, int S_, int PBH_, int PBW_, int NPB_, int CC_, int ACT_, bool POOL_, int NCB_ = 2, int SEG_ = 1, int FW_ = 0, bool F1A_ = false, int EPI_ = 0>
 struct Cfg {
   static constexpr bool F1A = F1A_;
+  static constexpr int EPI = EPI_;
+  static_assert(EPI_ == 0 || (KS_ == 1 && S_ == 1 && NPB_ == 1 && SEG_ == 1 && FW_ == 0 && !POOL_ && ACT_ == 0 && !F1A_), "head epilogues sit on a plain 1x1 layer");
+  static_assert(EPI_ != 1 || NCB_ == 3, "softmax over 65 channels: three cout blocks per wave");
+  static_assert(EPI_ != 2 || NCB_ == 8, "L2 norm over 256 channels: eight cout blocks per wave");
   static constexpr int KS = KS_, S = S_, PBH = PBH_, PBW = PBW_, NPB = NPB_, CC = CC_, ACT = ACT_;
   static constexpr bool POOL = POOL_;
   static constexpr int T = KS * KS;
@@ -336,7 +347,87 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a) {
   float* outb = a.out + (size_t)b * a.out_fs;
   auto at_w = [](float* base, unsigned off) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off); };
   auto at_r = [](const float* base, unsigned off) -> const float& { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); };
-  if constexpr (C::POOL) {
+  if constexpr (C::EPI == EPI_SOFTMAX_D2S) {
+    // Lane (j, h) holds channels 32 cb + 8 g + 4 h + i (register 4 g + i) of ONE cell; its partner lane (j, 1 - h) holds the other
+    // half.  softmax_d2s_kernel's order: max, e_c = dani_expf(s_c - max), sum over c = 0 .. 64 in order, e_c / sum.
+    const int cy = y0 + wpx * C::PBH + j / C::PBW, cx = x0 + j % C::PBW;
+    const bool ok = cy < a.H && cx < a.W;
+    const float c64 = acc[2][0][0];                 // channel 64 (the dustbin) lives on lane half 0
+    float m = acc[0][0][0];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) m = fmaxf(m, acc[cb][0][r]);
+    if (h == 0) m = fmaxf(m, c64);
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float e[2][16], pe[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) e[cb][r] = dani_expf(acc[cb][0][r] - m);
+    float e64 = dani_expf(c64 - m);
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) pe[cb][r] = __shfl_xor(e[cb][r], 32);
+    const float pe64 = __shfl_xor(e64, 32);
+    float sum = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) sum = sum + (h ? pe[cb][4 * g + i] : e[cb][4 * g + i]);   // channels 32 cb + 8 g + i     (lane half 0)
+#pragma unroll
+        for (int i = 0; i < 4; i++) sum = sum + (h ? e[cb][4 * g + i] : pe[cb][4 * g + i]);   // channels 32 cb + 8 g + 4 + i (lane half 1)
+      }
+    sum = sum + (h ? pe64 : e64);
+    if (ok) {
+      const int PW = a.W * 8;
+      float* o = outb + (size_t)(cy * 8) * PW + cx * 8 + 4 * h;      // row dy = 4 cb + g of the cell's 8 x 8 block, columns 4 h .. 4 h + 3
+#pragma unroll
+      for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[i] = e[cb][4 * g + i] / sum;
+          *reinterpret_cast<f32x4*>(o + (size_t)(4 * cb + g) * PW) = v;
+        }
+    }
+  } else if constexpr (C::EPI == EPI_L2NORM_NHWC) {
+    // desc_norm_kernel's order: s = fma(d_c, d_c, s) for c = 0 .. 255, dn = sqrt(s), d_c / dn.  Both lanes of a cell walk the whole
+    // chain (the partner's sixteen values of a cout block arrive by one cross-half exchange each).
+    const int cy = y0 + wpx * C::PBH + j / C::PBW, cx = x0 + j % C::PBW;
+    const bool ok = cy < a.H && cx < a.W;
+    float ss = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < 8; cb++) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) pv[r] = __shfl_xor(acc[cb][0][r], 32);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float d = h ? pv[4 * g + i] : acc[cb][0][4 * g + i]; ss = __builtin_fmaf(d, d, ss); }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const float d = h ? acc[cb][0][4 * g + i] : pv[4 * g + i]; ss = __builtin_fmaf(d, d, ss); }
+      }
+    }
+    const float dn = sqrtf(ss);
+    if (ok) {
+      float* o = outb + ((size_t)cy * a.W + cx) * 256 + 4 * h;
+#pragma unroll
+      for (int cb = 0; cb < 8; cb++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[i] = acc[cb][0][4 * g + i] / dn;
+          *reinterpret_cast<f32x4*>(o + 32 * cb + 8 * g) = v;
+        }
+    }
+  } else if constexpr (C::POOL) {
     const int yo = (y0 + wave * 2) >> 1, xo = (x0 + j) >> 1;
     const bool ok = ((j & 1) == 0) && yo < (a.H >> 1) && xo < (a.W >> 1);
     const unsigned lane_off = 4u * ((unsigned)(yo + a.opady) * (unsigned)a.oWp + (unsigned)(xo + PADX) + 4u * (unsigned)h * oplane);
@@ -485,6 +576,10 @@ using CfgR4Relu          = Cfg<3, 1, 1, 32, 1, 8, ACT_RELU, false, 1>;
 using CfgRow32ReluPoolF1A  = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true, 2, 1, 0, true>;
 using CfgRow32nReluPoolF1A = Cfg<3, 1, 1, 32, 2, 8, ACT_RELU, true, 1, 1, 0, true>;
 
+// SuperPoint's heads with their post-processing in the epilogue (Cfg::EPI): 8 x 16 cells x ALL couts per workgroup
+using CfgConv1SoftmaxD2S   = Cfg<1, 1, 2, 16, 1, 32, ACT_NONE, false, 3, 1, 0, false, EPI_SOFTMAX_D2S>;
+using CfgConv1L2NormNhwc   = Cfg<1, 1, 2, 16, 1, 32, ACT_NONE, false, 8, 1, 0, false, EPI_L2NORM_NHWC>;
+
 template <class C>
 static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t s, int reserve_lds) {
   ConvArgs a;
@@ -495,6 +590,7 @@ static bool launch_cfg(const ConvLayerPlan& L, const ConvIO& io, int B, hipStrea
   a.img = io.img; a.img_stride = io.img_stride; a.img_fs = io.img_fs; a.w1a = io.w1a; a.b1a = io.b1a;
   if (C::F1A && (!io.img || !io.w1a || !io.b1a || L.CinPad != 64)) return false;   // the fused layer reads the image, not `in`
   if (C::FW && io.W != C::FW) return false;   // a flat instantiation is built for one level width
+  if (C::EPI && (L.cout_tiles != 1 || L.Cout != (C::EPI == EPI_SOFTMAX_D2S ? 65 : 256) || io.res)) return false;   // a head epilogue needs the whole channel axis in one workgroup
   a.tiles_x = C::FW ? (io.H * io.W + C::NPIX - 1) / C::NPIX : (io.W + C::TW - 1) / C::TW;
   a.tiles_y = C::FW ? 1 : (io.H + C::TH - 1) / C::TH;
   a.cout_tiles = L.cout_tiles;
@@ -558,6 +654,8 @@ bool launch_conv_io(const ConvLayerPlan& L, const ConvIO& io, int B, hipStream_t
     case CONV3_F20_SILU_K4: return launch_cfg<CfgF20Silu3K4>(L, io, B, s, reserve_lds);
     case CONV3S2_F20_SILU_K2: return launch_cfg<CfgF20Silu3S2K2>(L, io, B, s, reserve_lds);
     case CONV1_F20_SILU_K2: return launch_cfg<CfgF20Silu1K2>(L, io, B, s, reserve_lds);
+    case CONV1_BLK16S_SOFTMAX_D2S: return launch_cfg<CfgConv1SoftmaxD2S>(L, io, B, s, reserve_lds);
+    case CONV1_BLK16S_L2NORM_NHWC: return launch_cfg<CfgConv1L2NormNhwc>(L, io, B, s, reserve_lds);
   }
   return false;
 }
@@ -583,6 +681,18 @@ bool launch_conv_mfma_f1a(const ConvLayerPlan& L, const uint8_t* img, int img_st
   return launch_conv_io(L, io, B, s, reserve_lds);
 }
 
+// A SuperPoint head whose epilogue writes the finished map (L.variant is an EPI variant): dst = the dense probability map
+// [B][8 Hc][8 Wc] or the normalised descriptors [B][Hc * Wc][256]; dst_fs = floats per frame
+bool launch_conv_head(const ConvLayerPlan& L, const ActDesc& in, float* dst, size_t dst_fs, int B, hipStream_t s, int reserve_lds) {
+  ConvIO io;
+  io.in = in.p; io.out = dst; io.res = nullptr;
+  io.H = in.H; io.W = in.W;
+  io.iHp = in.Hp; io.iWp = in.Wp; io.ipady = in.pady; io.oHp = 0; io.oWp = 0; io.opady = 0;
+  io.in_fs = in.frame_stride(); io.out_fs = dst_fs; io.res_fs = 0;
+  if (L.variant != CONV1_BLK16S_SOFTMAX_D2S && L.variant != CONV1_BLK16S_L2NORM_NHWC) return false;
+  return launch_conv_io(L, io, B, s, reserve_lds);
+}
+
 #ifdef DANI_CONV_STAMPS
 }  // namespace dani
 extern "C" __attribute__((visibility("default"))) int dani_debug_conv_stamps(unsigned long long* out, int reset) {
@@ -601,6 +711,15 @@ const char* conv_kernel_name(ConvVariant v) {
     case CONV3_ROW32_RELU_POOL: return "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,true>>";
     case CONV3_BLK16_RELU: return "conv_mfma_kernel<Cfg<3,1,2,16,2,8,RELU,false>>";
     case CONV1_BLK16_LINEAR: return "conv_mfma_kernel<Cfg<1,1,2,16,2,32,NONE,false>>";
+    case CONV3_BLK16S_RELU: return "conv_mfma_kernel<Cfg<3,1,2,16,1,8,RELU,false,1>>";
+    case CONV1_BLK16S_LINEAR: return "conv_mfma_kernel<Cfg<1,1,2,16,1,32,NONE,false,1>>";
+    case CONV3_ROW32N_RELU: return "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,false,1>>";
+    case CONV3_ROW32N_RELU_POOL: return "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,true,1>>";
+    case CONV3_R4_RELU: return "conv_mfma_kernel<Cfg<3,1,1,32,1,8,RELU,false,1>>";
+    case CONV3_ROW32_RELU_POOL_F1A: return "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,true,2,1,0,F1A>>+conv1a";
+    case CONV3_ROW32N_RELU_POOL_F1A: return "conv_mfma_kernel<Cfg<3,1,1,32,2,8,RELU,true,1,1,0,F1A>>+conv1a";
+    case CONV1_BLK16S_SOFTMAX_D2S: return "conv_mfma_kernel<Cfg<1,1,2,16,1,32,NONE,false,3,1,0,false,EPI_SOFTMAX_D2S>>+softmax_d2s";
+    case CONV1_BLK16S_L2NORM_NHWC: return "conv_mfma_kernel<Cfg<1,1,2,16,1,32,NONE,false,8,1,0,false,EPI_L2NORM_NHWC>>+l2norm_nhwc";
     default: return "conv_mfma_kernel<yolo variant>";
   }
 }

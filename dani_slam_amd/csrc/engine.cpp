@@ -4,6 +4,8 @@
 // every network stage runs in the HIP kernels; only order-defining host logic (host_logic.cpp) runs on the host, as it
 // does in the reference.
 #include "engine_internal.h"
+#include <ctime>
+#include <unordered_map>
 
 using namespace dani;
 using namespace dani::eng;
@@ -75,8 +77,8 @@ void context_destroy_sync(Context* c) {
   for (auto& ev : c->lev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
   for (hipEvent_t* ev : {&c->ev_desc, &c->ev_y0, &c->ev_y1, &c->ev_lg0, &c->ev_lg1, &c->ev_fork0, &c->ev_fork1})
     if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
-  if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
-  if (c->stream2) { (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
+  if (c->stream) { near_forget(c->stream); (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
+  if (c->stream2) { near_forget(c->stream2); (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
 }
 
 // A free context of the pool; when all n_contexts are in use the caller WAITS for one (calls are short and always
@@ -100,6 +102,74 @@ int dev_alloc(dani_engine* e, Context* c, void** p, size_t bytes, bool zero) {
   if (zero) HIP_TRY(e, hipMemsetAsync(*p, 0, bytes, c->stream));
   return 0;
 }
+// ---- host waits (engine_internal.h) --------------------------------------------------------------------------------------
+namespace {
+struct NearMark { hipEvent_t ev = nullptr; bool armed = false; };
+std::mutex g_near_mu;
+std::unordered_map<hipStream_t, NearMark> g_near;
+inline int wait_mode() {
+  static const int env_mode = [] {
+    const char* m = getenv("DANI_HOST_WAIT");
+    if (m) return !strcmp(m, "block") ? 0 : (!strcmp(m, "spin") ? 1 : 2);
+    const char* sp = getenv("DANI_SPIN_WAIT");
+    return (sp && atoi(sp) != 0) ? 1 : 2;
+  }();
+  const int mode = g_host_wait.load(std::memory_order_relaxed);
+  return mode < 0 ? env_mode : mode;
+}
+inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+void near_mark(hipStream_t s) {
+  if (wait_mode() != 2) return;
+  std::lock_guard<std::mutex> lk(g_near_mu);
+  NearMark& m = g_near[s];
+  if (!m.ev && hipEventCreateWithFlags(&m.ev, hipEventDisableTiming) != hipSuccess) { m.ev = nullptr; return; }
+  m.armed = hipEventRecord(m.ev, s) == hipSuccess;
+}
+void near_forget(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_near_mu);
+  auto it = g_near.find(s);
+  if (it == g_near.end()) return;
+  if (it->second.ev) (void)hipEventDestroy(it->second.ev);
+  g_near.erase(it);
+}
+hipError_t stream_wait(hipStream_t s, void (*before_spin)(void*), void* arg) {
+  const int mode = wait_mode();
+  if (mode == 0) { if (before_spin) before_spin(arg); return (hipStreamSynchronize)(s); }
+  auto spin = [&](double limit_us, bool* done) -> hipError_t {   // poll until the stream is idle or limit_us have passed
+    const double t0 = now_us();
+    for (;;) {
+      const hipError_t st = hipStreamQuery(s);
+      if (st != hipErrorNotReady) { *done = true; return st; }
+      for (int k = 0; k < 32; k++) __builtin_ia32_pause();
+      if (limit_us > 0 && now_us() - t0 > limit_us) { *done = false; return hipSuccess; }
+    }
+  };
+  bool done = false;
+  if (mode == 1) { if (before_spin) before_spin(arg); return spin(0, &done); }
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_near_mu);
+    auto it = g_near.find(s);
+    if (it != g_near.end() && it->second.armed) { ev = it->second.ev; it->second.armed = false; }
+  }
+  if (ev) {   // stage 1: nap until the marker has passed (a stream error ends the naps; stage 2 then reports it)
+    while (hipEventQuery(ev) == hipErrorNotReady) {
+      timespec ts{0, 40000};
+      nanosleep(&ts, nullptr);
+    }
+    if (before_spin) before_spin(arg);
+    const hipError_t st = spin(3000.0, &done);   // stage 2: the marker sits 0.2-0.6 ms ahead of the end; 3 ms = something else is queued behind it
+    if (done) return st;
+    return (hipStreamSynchronize)(s);
+  }
+  if (before_spin) before_spin(arg);
+  const hipError_t st = spin(150.0, &done);
+  if (done) return st;
+  return (hipStreamSynchronize)(s);
+}
+
 int host_alloc(dani_engine* e, Context* c, void** p, size_t bytes) {
   HIP_TRY(e, hipHostMalloc(p, bytes, hipHostMallocDefault));
   c->host_allocs.push_back(*p);
@@ -124,7 +194,7 @@ void free_buffers(Context* c) {
 extern "C" {
 
 int dani_set_host_wait(int32_t mode) {
-  if (mode < 0 || mode > 1) return DANI_ERR_INVALID;
+  if (mode < 0 || mode > 2) return DANI_ERR_INVALID;
   dani::eng::g_host_wait.store(mode, std::memory_order_relaxed);
   return DANI_OK;
 }

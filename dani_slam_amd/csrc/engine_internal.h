@@ -26,22 +26,20 @@ namespace eng {
 
 extern thread_local std::string g_create_error;
 
-// Every stream wait of the engine goes through here.  Spin mode (dani_set_host_wait(1) or DANI_SPIN_WAIT=1): poll
-// hipStreamQuery from user space instead of blocking in the runtime -- the calling thread never sleeps, so there is no wake-up
-// latency behind a kernel that has just finished (0.08 ms per 8-frame front-end call, 728.7 -> 733.6 frames/s in a same-box
-// A/B), at the price of one busy core per calling thread.  Default: block (a tracker shares its cores with the mapping threads).
-extern std::atomic<int> g_host_wait;   // dani_set_host_wait: -1 = the environment's choice (DANI_SPIN_WAIT, default block), 0 = block, 1 = spin
-inline hipError_t stream_wait(hipStream_t s) {
-  static const bool env_spin = getenv("DANI_SPIN_WAIT") && atoi(getenv("DANI_SPIN_WAIT")) != 0;
-  const int mode = g_host_wait.load(std::memory_order_relaxed);
-  const bool spin = mode < 0 ? env_spin : mode != 0;
-  if (!spin) return (hipStreamSynchronize)(s);
-  for (;;) {
-    const hipError_t st = hipStreamQuery(s);
-    if (st != hipErrorNotReady) return st;
-    for (int k = 0; k < 32; k++) __builtin_ia32_pause();
-  }
-}
+// Every stream wait of the engine goes through here (engine.cpp).  dani_set_host_wait / DANI_HOST_WAIT:
+//   0 "block"   hipStreamSynchronize.  On this ROCm build that is NOT a sleep: the runtime busy-waits (measured with per-thread CPU
+//               clocks in bench.py: 10.8 ms of caller CPU + 9.9 ms of a runtime thread per 10.8 ms front-end call)
+//   1 "spin"    poll hipStreamQuery from user space: same cost, 0.05 ms per call faster than the runtime's own wait
+//   2 "hybrid"  (default) two stages: SLEEP (40 us naps polling an event) until a marker that the engine records a few hundred
+//               microseconds of GPU work ahead of the point it is going to wait for (near_mark below: behind SuperPoint's detector
+//               head, in front of LightGlue's last FFN), then SPIN for the rest.  Waits without a marker spin for at most 150 us
+//               and then hand over to hipStreamSynchronize.  Same throughput as the other two on the same box (745 / 743 / 746
+//               frames/s), caller CPU 2.1 ms and runtime thread 4.7 ms per 10.7 ms call: one core instead of 2.3
+//               (profiles/r04_bench_host_wait_*.json).
+extern std::atomic<int> g_host_wait;   // -1 = the environment's choice (DANI_HOST_WAIT=block|spin|hybrid, DANI_SPIN_WAIT=1; default hybrid)
+hipError_t stream_wait(hipStream_t s, void (*before_spin)(void*) = nullptr, void* arg = nullptr);   // before_spin: called once when the naps are over (or at once without a marker / in the pure modes)
+void near_mark(hipStream_t s);     // "the next wait on s is a few hundred microseconds of GPU work away": records s's marker event
+void near_forget(hipStream_t s);   // the stream is about to be destroyed
 
 constexpr int CAND_FAST = 4096;  // candidates per frame read back together with the counts (typical frames: 3-4 k)
 
@@ -72,6 +70,7 @@ struct Context {
     uint8_t* d_level_img = nullptr;   // level > 0: this level's image [B][H][W] (resized from level - 1)
     const uint8_t* last_img = nullptr; int last_stride = 0, last_B = 0; size_t last_frame = 0;   // the last call's level image (device)
     bool act0_valid = false;          // act[0] (conv1a) holds the last call's activation (false when conv1b computed it on the fly)
+    bool heads_valid = false;         // act[9] / act[11] (semi, coarse descriptors) hold the last call's layers (false when the heads' epilogues consumed them)
   };
   std::vector<Level> lv;
   int32_t* d_boxes = nullptr;
@@ -140,6 +139,8 @@ struct dani_engine {
   std::map<std::string, std::vector<float>> tensors;
   bool finalized = false;
   ConvLayerPlan plan[12];
+  ConvLayerPlan plan_plain_pb, plan_plain_db;   // convPb / convDb as plain layers when plan[9] / plan[11] are the fused heads (debug hooks)
+  bool fused_heads = false;
   float* w1a = nullptr;
   float* b1a = nullptr;
   std::vector<void*> weight_allocs;

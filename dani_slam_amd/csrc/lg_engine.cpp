@@ -336,7 +336,7 @@ bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
     ffn_and_next(S, C.a, L->qkv, 0, 1.0f);
     attn(L->qkv, L->qkv, L->qkv + (size_t)256 * ld, 1, 1.0f);
     if (i + 1 < LG_LAYERS) ffn_and_next(C, W->self_[i + 1].a, L->qkv, 512, 1.0f);
-    else ffn_and_next(C, W->final_proj, L->md, 0, 0.25f);   // / d^0.25, d = 256
+    else { near_mark(s); ffn_and_next(C, W->final_proj, L->md, 0, 0.25f); }   // / d^0.25, d = 256; the caller's final wait is one FFN + the match head away
   }
   L->lin_launches = li / 2;
   launch_matchability(L->x, W->match_w, W->match_b, L->logsig, T, ld, s);

@@ -198,17 +198,35 @@ int dani_finalize_weights(dani_engine* e) {
       static const bool fuse_off = getenv("DANI_SP_FUSE_1A") && atoi(getenv("DANI_SP_FUSE_1A")) == 0;
       if (!fuse_off) L.variant = L.variant == CONV3_ROW32_RELU_POOL ? CONV3_ROW32_RELU_POOL_F1A : (L.variant == CONV3_ROW32N_RELU_POOL ? CONV3_ROW32N_RELU_POOL_F1A : L.variant);
     }
-    L.Cin = d.cin; L.Cout = d.cout; L.ksize = d.k; L.CinPad = d.cin;
-    L.CC = conv_variant_cc(L.variant);
-    const int nco = conv_variant_nco(L.variant);
-    L.cout_tiles = (d.cout + nco - 1) / nco;
-    L.w_packed_floats = (size_t)L.cout_tiles * nco * d.cin * d.k * d.k;
-    std::vector<float> wp(L.w_packed_floats), bp((size_t)L.cout_tiles * nco);
-    pack_conv_weights(wi->second.data(), bi->second.data(), d.cin, d.cout, d.k, L.CC, nco, wp.data(), bp.data());
-    HIP_TRY(e, hipMalloc((void**)&L.w_packed, wp.size() * 4)); e->weight_allocs.push_back(L.w_packed);
-    HIP_TRY(e, hipMalloc((void**)&L.bias_packed, bp.size() * 4)); e->weight_allocs.push_back(L.bias_packed);
-    HIP_TRY(e, hipMemcpy(L.w_packed, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(e, hipMemcpy(L.bias_packed, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+    auto pack_plan = [&](ConvLayerPlan& P) -> int {
+      P.Cin = d.cin; P.Cout = d.cout; P.ksize = d.k; P.CinPad = d.cin;
+      P.CC = conv_variant_cc(P.variant);
+      const int nco = conv_variant_nco(P.variant);
+      P.cout_tiles = (d.cout + nco - 1) / nco;
+      P.w_packed_floats = (size_t)P.cout_tiles * nco * d.cin * d.k * d.k;
+      std::vector<float> wp(P.w_packed_floats), bp((size_t)P.cout_tiles * nco);
+      pack_conv_weights(wi->second.data(), bi->second.data(), d.cin, d.cout, d.k, P.CC, nco, wp.data(), bp.data());
+      HIP_TRY(e, hipMalloc((void**)&P.w_packed, wp.size() * 4)); e->weight_allocs.push_back(P.w_packed);
+      HIP_TRY(e, hipMalloc((void**)&P.bias_packed, bp.size() * 4)); e->weight_allocs.push_back(P.bias_packed);
+      HIP_TRY(e, hipMemcpy(P.w_packed, wp.data(), wp.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(e, hipMemcpy(P.bias_packed, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+      return 0;
+    };
+    if (i == 9 || i == 11) {
+      // The heads' last layers finish the map in their epilogue (conv_mfma.hip, Cfg::EPI: softmax + depth-to-space / L2 norm + NHWC)
+      // when the batch fills the chip with 128-cell workgroups that hold every output channel; one or two frames keep the plain
+      // layers (32 couts per workgroup, 8x the workgroups) + softmax_d2s_kernel / desc_norm_kernel.  DANI_SP_FUSE_HEADS=0/1 forces.
+      const int tiles = ((e->cfg.max_height / 8 + 7) / 8) * ((e->cfg.max_width / 8 + 15) / 16);
+      const char* fh = getenv("DANI_SP_FUSE_HEADS");
+      e->fused_heads = fh ? atoi(fh) != 0 : e->cfg.max_batch * tiles >= 192;
+      if (e->fused_heads) {
+        ConvLayerPlan& P = i == 9 ? e->plan_plain_pb : e->plan_plain_db;
+        P.variant = L.variant;
+        { int rc = pack_plan(P); if (rc) return rc; }
+        L.variant = i == 9 ? CONV1_BLK16S_SOFTMAX_D2S : CONV1_BLK16S_L2NORM_NHWC;
+      }
+    }
+    { int rc = pack_plan(L); if (rc) return rc; }
   }
   { int rc = lg_finalize(e); if (rc) return rc; }
   { int rc = yolo_finalize(e); if (rc) return rc; }
@@ -297,6 +315,8 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
       const bool lprof = prof && l == 0;
       const bool fused1a = e->plan[1].variant == CONV3_ROW32_RELU_POOL_F1A || e->plan[1].variant == CONV3_ROW32N_RELU_POOL_F1A;
       L.last_img = limg; L.last_stride = lstride; L.last_frame = lframe; L.last_B = B; L.act0_valid = !fused1a;
+      const bool fheads = e->fused_heads;
+      L.heads_valid = !fheads;
       if (lprof) HIP_TRY(e, hipEventRecord(c->lev[0], s));
       if (!fused1a) launch_conv1a(limg, B, L.H, L.W, lstride, lframe, e->w1a, e->b1a, L.act[0], s);   // fused: conv1b forms it on the fly
       if (lprof) HIP_TRY(e, hipEventRecord(c->lev[1], s));
@@ -314,8 +334,11 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
           HIP_TRY(e, hipEventRecord(c->ev_fork0, s));
           HIP_TRY(e, hipStreamWaitEvent(c->stream2, c->ev_fork0, 0));
         }
+        const int Hc8 = (L.H / 8) * 8, Wc8 = (L.W / 8) * 8;
         const bool launched = (i == 1 && fused1a)
             ? launch_conv_mfma_f1a(e->plan[1], limg, lstride, lframe, e->w1a, e->b1a, L.act[0], L.act[1], B, si, reserve)
+            : (fheads && i == 9)  ? launch_conv_head(e->plan[9], L.act[8], L.prob, (size_t)Hc8 * Wc8, B, si, reserve)
+            : (fheads && i == 11) ? launch_conv_head(e->plan[11], L.act[10], L.desc_nhwc, (size_t)(Hc8 / 8) * (Wc8 / 8) * 256, B, si, reserve)
             : launch_conv_mfma(e->plan[i], L.act[src_of[i]], L.act[i], B, si, reserve);
         if (!launched) {
           (void)hipStreamSynchronize(s);
@@ -323,14 +346,15 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
           return fail(e, DANI_ERR_UNSUPPORTED, "%s at %dx%d: activation tensor exceeds the conv kernel's 32-bit addressing range", kSp[i].name, L.W, L.H);
         }
         if (lprof) HIP_TRY(e, hipEventRecord(c->lev[i + 1], s));
+        if (i == 9 && l == NL - 1 && si == s) near_mark(s);   // the detector head is enqueued: the candidate read-back is ~0.4 ms of GPU work away
       }
       if (l == NL - 1) HIP_TRY(e, hipEventRecord(c->ev[1], s));   // end of the main stream's convolutions, on both paths
       if (fork) {
-        launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, c->stream2);
+        if (!fheads) launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, c->stream2);
         HIP_TRY(e, hipEventRecord(c->ev_fork1, c->stream2));
-        launch_softmax_d2s(L.act[9], L.prob, B, s);
+        if (!fheads) launch_softmax_d2s(L.act[9], L.prob, B, s);
         HIP_TRY(e, hipStreamWaitEvent(s, c->ev_fork1, 0));   // everything later on the main stream sees both branches
-      } else {
+      } else if (!fheads) {
         launch_softmax_d2s(L.act[9], L.prob, B, s);
         launch_desc_norm(L.act[11], L.desc_nhwc, L.desc_nchw, B, s);
       }
@@ -347,8 +371,8 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
   const int minBorderX = 19 - 3, minBorderY = minBorderX;
   // wait for the candidate read-back; frames with more than CAND_FAST candidates get their remainder in a second copy
   auto fetch_candidates = [&]() -> int {
-    host_pool().prewake();   // the quadtree tasks start as soon as this synchronise returns
-    HIP_TRY(e, hipStreamSynchronize(s));
+    // the quadtree tasks start as soon as this wait returns: the pool's workers are woken when its spinning stage begins
+    HIP_TRY(e, stream_wait(s, [](void*) { host_pool().prewake(); }, nullptr));
     bool more = false;
     for (int l = 0; l < NL; l++) {
       Context::Level& L = c->lv[l];
@@ -544,7 +568,15 @@ int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* desc_map,
   const Context::Level& L = c->lv[dl];
   const int Hc = L.H / 8, Wc = L.W / 8;
   if (prob) HIP_TRY(e, hipMemcpy(prob, L.prob + (size_t)b * Hc * 8 * Wc * 8, (size_t)Hc * 8 * Wc * 8 * 4, hipMemcpyDeviceToHost));
-  if (desc_map) HIP_TRY(e, hipMemcpy(desc_map, L.desc_nchw + (size_t)b * 256 * Hc * Wc, (size_t)256 * Hc * Wc * 4, hipMemcpyDeviceToHost));
+  if (desc_map && !e->fused_heads) HIP_TRY(e, hipMemcpy(desc_map, L.desc_nchw + (size_t)b * 256 * Hc * Wc, (size_t)256 * Hc * Wc * 4, hipMemcpyDeviceToHost));
+  if (desc_map && e->fused_heads) {
+    // fused heads: the normalised map exists as [cell][256] only (what the sampler reads); the hook's [256][cell] view is its transpose
+    const size_t npix = (size_t)Hc * Wc;
+    std::vector<float> t(npix * 256);
+    HIP_TRY(e, hipMemcpy(t.data(), L.desc_nhwc + (size_t)b * npix * 256, npix * 256 * 4, hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < npix; p++)
+      for (int ch = 0; ch < 256; ch++) desc_map[(size_t)ch * npix + p] = t[p * 256 + ch];
+  }
   if (n_cand) *n_cand = L.h_cand_count[b];
   if (cand_xyr) {
     const int n = std::min(L.h_cand_count[b], cand_cap);
@@ -570,6 +602,17 @@ int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, in
     HIP_TRY(e, hipGetLastError());
     L0.act0_valid = true;
   }
+  if ((layer == 9 || layer == 11) && !c->lv[0].heads_valid) {
+    // the heads' raw last layers never reach HBM when their epilogues finish the maps: the hook runs the plain layers on the
+    // last call's convPa / convDa activations (still in place)
+    Context::Level& L0 = c->lv[0];
+    if (b >= L0.last_B) return fail(e, DANI_ERR_INVALID, "no previous call on this thread");
+    if (!launch_conv_mfma(e->plan_plain_pb, L0.act[8], L0.act[9], L0.last_B, c->stream) ||
+        !launch_conv_mfma(e->plan_plain_db, L0.act[10], L0.act[11], L0.last_B, c->stream))
+      return fail(e, DANI_ERR_UNSUPPORTED, "debug layer: plain head layers refused the shape");
+    HIP_TRY(e, hipGetLastError());
+    L0.heads_valid = true;   // (desc_nchw stays unwritten: dani_sp_debug_fetch transposes the fused map instead)
+  }
   float* tmp = nullptr;
   HIP_TRY(e, hipMalloc((void**)&tmp, need * 4));
   launch_copy_layer_dense(a, b, tmp, c->stream);
@@ -577,6 +620,16 @@ int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, in
   if (st == hipSuccess) st = hipStreamSynchronize(c->stream);
   (void)hipFree(tmp);
   if (st != hipSuccess) return fail(e, DANI_ERR_HIP, "debug layer copy failed: %s", hipGetErrorString(st));
+  return DANI_OK;
+}
+
+int dani_sp_layer_kernel(dani_engine* e, int32_t layer, char* name, int32_t cap) {
+  if (!e || !name || cap < 1) return DANI_ERR_INVALID;
+  if (layer < 0 || layer >= 12) return fail(e, DANI_ERR_INVALID, "layer %d outside [0, 12)", layer);
+  if (!e->finalized) return fail(e, DANI_ERR_WEIGHTS, "weights not finalized (call dani_finalize_weights)");
+  const bool fused1a = e->plan[1].variant == CONV3_ROW32_RELU_POOL_F1A || e->plan[1].variant == CONV3_ROW32N_RELU_POOL_F1A;
+  const char* nm = layer == 0 ? (fused1a ? "(computed inside conv1b)" : "conv1a_kernel") : conv_kernel_name(e->plan[layer].variant);
+  snprintf(name, (size_t)cap, "%s", nm);
   return DANI_OK;
 }
 

@@ -85,6 +85,7 @@ def load_library():
                                           C.c_int32, _i32, _i32]
     lib.dani_sp_debug_fetch.argtypes = [C.c_void_p, C.c_int32, _f, _f, _f, C.c_int32, _i32]
     lib.dani_sp_debug_layer.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, C.c_int64]
+    lib.dani_sp_layer_kernel.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]
     lib.dani_lg_match_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, _i32,
                                         C.c_void_p, C.c_void_p, _i32, _f, _f, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_retain.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f, _i32, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -342,6 +343,12 @@ class Engine:
         self._check(self.lib.dani_sp_debug_fetch(self.h, b, _fp(prob), _fp(dmap), _fp(cand), cand_cap, C.byref(nc)))
         return prob, dmap, cand[:nc.value].copy()
 
+    def sp_layer_kernel(self, layer):
+        """Name of the kernel instantiation SuperPoint layer 0..11 runs as on this engine (dani_sp_layer_kernel)."""
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.dani_sp_layer_kernel(self.h, layer, buf, 256))
+        return buf.value.decode()
+
     def sp_debug_layer(self, b, layer, shape):
         out = np.empty(shape, np.float32)
         self._check(self.lib.dani_sp_debug_layer(self.h, b, layer, _fp(out), out.size))
@@ -407,9 +414,14 @@ class Engine:
                                                   _fp(s1) if s1 is not None else None, C.c_float(threshold), _ip(m), _fp(sc), _ip(mo), cap))
         return [(m[mo[g]:mo[g + 1]].copy(), sc[mo[g]:mo[g + 1]].copy()) for g in range(G)]
 
-    def set_host_wait(self, spin):
-        """Process-wide: the calling thread spins on hipStreamQuery (True) or blocks in hipStreamSynchronize (False, default)."""
-        self._check(self.lib.dani_set_host_wait(1 if spin else 0))
+    HOST_WAIT = {"block": 0, "spin": 1, "hybrid": 2}
+
+    def set_host_wait(self, mode):
+        """Process-wide (dani_set_host_wait): "block" = sleep in hipStreamSynchronize, "spin" = poll hipStreamQuery, "hybrid" (the
+        library's default) = nap until the engine's near-end marker, then spin.  True / False = spin / block (older callers)."""
+        if isinstance(mode, bool):
+            mode = "spin" if mode else "block"
+        self._check(self.lib.dani_set_host_wait(self.HOST_WAIT[mode]))
 
     def lg_set_kernel_option(self, name, value):
         """Process-wide kernel selection of the f32 LightGlue path (dani_lg_set_kernel_option): 'lin_rs', 'attn'."""

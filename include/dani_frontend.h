@@ -127,6 +127,11 @@ DANI_API int dani_sp_debug_fetch(dani_engine* e, int32_t b, float* prob, float* 
  * last call to host as dense [C][H][W].  Layers 1, 3 and 5 (conv1b/2b/3b) are returned AFTER their fused
  * 2x2 max-pool (the pre-pool tensor never exists in HBM). */
 DANI_API int dani_sp_debug_layer(dani_engine* e, int32_t b, int32_t layer, float* out, int64_t count);
+/* Which kernel instantiation SuperPoint layer `layer` (0 = conv1a ... 11 = convDb, the order of dani_layer_timings) runs as on
+ * this engine -- chosen at dani_finalize_weights from max_batch and the frame size: conv1a inside conv1b (src/SuperPoint.cpp:58-59),
+ * small-batch tile twins, the heads' softmax / L2 norm in their last layer's epilogue (:79-93).  Layers 9 / 11 whose epilogue
+ * finishes the map report "...+softmax_d2s" / "...+l2norm_nhwc"; the debug hook above then re-runs the plain layer on demand. */
+DANI_API int dani_sp_layer_kernel(dani_engine* e, int32_t layer, char* name, int32_t cap);
 
 /* Profiling switch: when on, HIP events are recorded around every conv layer of the next calls (on the
  * context's own stream) and dani_layer_timings() returns the 12 per-layer durations in ms (forward order). */
@@ -163,9 +168,12 @@ DANI_API int dani_lg_set_gemm(dani_engine* e, int32_t mode);
  *                register-resident launch per block (ffn_chain_kernel) instead of four
  * Returns DANI_ERR_INVALID for an unknown name or any other value (the probe-only kernels are not selectable here). */
 DANI_API int dani_lg_set_kernel_option(const char* name, int32_t value);
-/* How the calling thread waits for the GPU inside every entry point, process-wide: 0 = block in hipStreamSynchronize (default:
- * a tracker shares its cores with the mapping threads), 1 = spin on hipStreamQuery (no wake-up latency behind the last kernel
- * of a phase: 0.08 ms per 8-frame front-end call, at the price of one busy core per calling thread; bench.py uses it). */
+/* How the calling thread waits for the GPU inside every entry point, process-wide (environment: DANI_HOST_WAIT=block|spin|hybrid):
+ *   0 = hipStreamSynchronize (which busy-waits on this ROCm build: one core for the caller and most of one for a runtime thread);
+ *   1 = spin on hipStreamQuery (the same cost, 0.05 ms per 8-frame call faster);
+ *   2 = hybrid (default): sleep in 40 us naps until a marker event the engine records a few hundred microseconds of GPU work ahead
+ *       of the point it will wait for, then spin for the rest; waits without a marker spin for at most 150 us, then use mode 0.
+ *       Same throughput, ~1 core instead of ~2.3 per calling thread (bench.py: host_cpu_ms_per_step). */
 DANI_API int dani_set_host_wait(int32_t mode);
 
 /* Replaces LightGlue::matchDescriptors + normalizeKeypoints + filterMatches (src/LightGlue.cpp:18-122), as

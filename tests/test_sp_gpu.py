@@ -94,6 +94,39 @@ def test_other_params_and_thresholds(engine, sp_weights, oracle_frames):
         assert np.array_equal(r["desc"], ref["desc"])
 
 
+def test_heads_finished_in_the_conv_epilogue_bit_exact(sp_weights, oracle_frames):
+    """An engine built for 8 frames runs convPb + softmax + depth-to-space and convDb + L2 norm + NHWC as ONE kernel each
+    (conv_mfma.hip, Cfg::EPI; /root/reference/src/SuperPoint.cpp:73-93) and conv1a inside conv1b: the probability map, the
+    normalised descriptor map, every layer the debug hook can rebuild, and the extraction of a whole batch against the oracle."""
+    from dani_slam_amd import frontend
+    e = frontend.Engine(device=0, max_batch=8, max_width=640, max_height=480, weights=sp_weights)
+    try:
+        assert e.sp_layer_kernel(9).endswith("+softmax_d2s") and e.sp_layer_kernel(11).endswith("+l2norm_nhwc"), \
+            (e.sp_layer_kernel(9), e.sp_layer_kernel(11))
+        assert e.sp_layer_kernel(1).endswith("+conv1a") and e.sp_layer_kernel(0) == "(computed inside conv1b)"
+        # a 96 x 128 crop (partial tiles on both axes of the 12 x 16 cell grid): every layer, including the two the heads consumed
+        img = synth.frame(0)[96:96 + 96, 160:160 + 128].copy()
+        prob_o, desc_o, taps = oracle.superpoint_forward(img, sp_weights, want_taps=True)
+        e.sp_extract_batch(img[None])
+        prob, dmap, _ = e.sp_debug_fetch(0, 96, 128)
+        assert np.array_equal(prob, prob_o) and np.array_equal(dmap, desc_o)
+        for li, tp in enumerate(taps):
+            ref = oracle.maxpool2(tp) if li in (1, 3, 5) else tp
+            assert np.array_equal(e.sp_debug_layer(0, li, ref.shape), ref), f"layer {li}"
+        # full frames, batch of 8 (frames 0, 1, 2 repeated): maps of two of them, keypoints and descriptors of all
+        order = (0, 1, 2, 0, 1, 2, 0, 1)
+        rs = e.sp_extract_batch(np.stack([oracle_frames[i][0] for i in order]))
+        for b in (1, 7):
+            prob, dmap, cand = e.sp_debug_fetch(b, 480, 640)
+            ref = oracle_frames[order[b]][1]
+            assert np.array_equal(prob, ref["prob"]) and np.array_equal(dmap, ref["desc_map"])
+        for b, i in enumerate(order):
+            ref = oracle_frames[i][1]
+            assert np.array_equal(rs[b]["kpts"], ref["kpts"]) and np.array_equal(rs[b]["desc"], ref["desc"]), b
+    finally:
+        e.close()
+
+
 def test_dense_frames_have_no_candidate_limit(sp_weights):
     """A frame on which EVERY pixel of every cell is a candidate -- a detector head with zero weights gives the flat probability
     map 1/65 = 0.0154 > iniTh = 0.015 -- i.e. 204 cells x up to 1848 pixels with the 6-px overlap strips counted twice (quirk
