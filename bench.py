@@ -170,11 +170,11 @@ def main():
                          "sequence's stream, csrc/comm_engine.cpp; default with the nccl backend), torch = torch.distributed's "
                          "all_gather_into_tensor (the form of rounds 2-3; always used by the gloo rehearsal on one device)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the extra bf16x3 / batch-1 measurements (profiling runs)")
-    ap.add_argument("--host-wait", choices=("hybrid", "spin", "block"), default="hybrid",
-                    help="how the calling thread waits for the GPU inside the engine (dani_set_host_wait): hybrid = the library's default "
-                         "(the headline uses what a caller gets without asking): naps until the engine's near-end marker, then spins, "
-                         "~0.5 ms of busy core per 8-frame call; block = sleep in hipStreamSynchronize; spin = poll hipStreamQuery, one "
-                         "busy core per rank.  A default N = 1 run reports the other two as the side modes `host_wait_block` / `host_wait_spin`")
+    ap.add_argument("--host-wait", choices=("library", "hybrid", "spin", "block"), default="library",
+                    help="how the calling thread waits for the GPU inside the engine (dani_set_host_wait): library = whatever the library "
+                         "does when nobody asks (the headline; today: spin on hipStreamQuery); block = hipStreamSynchronize; hybrid = naps "
+                         "until the engine's near-end marker, then spins (one host core instead of 2.3).  A default N = 1 run reports the "
+                         "other modes as `host_wait_block` / `host_wait_hybrid` / `host_wait_spin`, each with its host CPU time per step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -210,7 +210,9 @@ def main():
     weights = synth.bench_weights()
     eng = frontend.Engine(device=local_rank, max_batch=max(B, 2), max_width=W, max_height=H, weights=weights)
     eng.yolo_set_classes(synth.COCO_NAMES, synth.DYNAMIC_NAMES)   # coco.names is not shipped by the reference
-    eng.set_host_wait(args.host_wait)
+    if args.host_wait != "library":
+        eng.set_host_wait(args.host_wait)
+    wait_in_force = eng.host_wait()
     if args.lg_gemm != "f32":
         eng.lg_set_gemm(eng.LG_GEMM_BF16X3 if args.lg_gemm == "bf16x3" else eng.LG_GEMM_BF16X3_ALL)
 
@@ -446,21 +448,24 @@ def main():
                          "note": f"dani_lg_set_gemm({key[8:].upper()}): {what} as six bf16 MFMAs over three-term operand splits, "
                                  "f32 accumulation; opt-in, not the headline"}
         eng.lg_set_gemm(eng.LG_GEMM_F32)
-        for hw in ("block", "spin"):   # the two pure wait modes, same workload, after the timed region
-            if hw == args.host_wait:
+        for hw in ("block", "hybrid", "spin"):   # the other wait modes, same workload, after the timed region
+            if hw == wait_in_force:
                 continue
             eng.set_host_wait(hw)
             run_steps(20, False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
+            c1 = time.process_time()
             _, _, _, _, _, sms = run_steps(SIDE_STEPS, False)
+            c2 = time.process_time()
             torch.cuda.synchronize()
             dts = time.perf_counter() - t1
-            eng.set_host_wait(args.host_wait)
+            eng.set_host_wait(wait_in_force)
             side["host_wait_" + hw] = {"value": round(B * SIDE_STEPS / dts, 3), "unit": "frames/s", "steps": SIDE_STEPS,
-                                       "ms_per_step": round(dts / SIDE_STEPS * 1e3, 4), "ms_per_step_median": pct(sms, 50),
-                                       "note": ("dani_set_host_wait(0): the calling thread sleeps in hipStreamSynchronize" if hw == "block" else
-                                                "dani_set_host_wait(1): the calling thread polls hipStreamQuery (one busy core per rank)") + "; opt-in, not the headline"}
+                                       "ms_per_step": round(dts / SIDE_STEPS * 1e3, 4), "ms_per_step_median": pct(sms, 50), "ms_per_step_max": pct(sms, 100),
+                                       "host_cpu_ms_per_step": round((c2 - c1) / SIDE_STEPS * 1e3, 3),
+                                       "note": {"block": "dani_set_host_wait(0): hipStreamSynchronize", "spin": "dani_set_host_wait(1): the calling thread polls hipStreamQuery",
+                                                "hybrid": "dani_set_host_wait(2): naps until the engine's near-end marker, then polls"}[hw] + "; not the headline"}
         # BASELINE configs #2 and #3: one call at a time, as a live tracker issues them (src/Frame.cc:420-427, :813-860), on an
         # engine built for that use (max_batch = 2: the engines pick their tile shapes for the batch they are built for)
         lat = {}
@@ -497,9 +502,9 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.lg_gemm == "f32" else f"f32 (LightGlue matrix products: {args.lg_gemm} operand split on the bf16 MFMA, f32 accumulate)", "data": "synthetic" + (" (frames handed over as HOST buffers: PCIe-inclusive)" if args.host_inputs else ""),
-            "host_wait": args.host_wait + {"hybrid": " (the library's default, dani_set_host_wait(2): naps until the engine's near-end marker, then polls hipStreamQuery)",
-                                           "spin": " (dani_set_host_wait(1): the calling thread polls hipStreamQuery instead of sleeping in hipStreamSynchronize)",
-                                           "block": " (dani_set_host_wait(0): hipStreamSynchronize)"}[args.host_wait],
+            "host_wait": wait_in_force + (" (the library's default)" if args.host_wait == "library" else " (asked for with --host-wait)") +
+                         {"hybrid": ": naps until the engine's near-end marker, then polls hipStreamQuery", "spin": ": the calling thread polls hipStreamQuery",
+                          "block": ": hipStreamSynchronize"}[wait_in_force],
             "host_cpu_ms_per_step": round((cpu1 - cpu0) / args.steps * 1e3, 3),   # CPU time of the whole process (caller, engine pool, runtime threads) inside the timed region
             "host_cpu_ms_per_step_top_threads": [[ms, nm] for ms, nm in cpu_by_thread if ms > 0.0],   # 10 ms clock ticks: coarse
             "step_ms": {"median": pct(step_ms, 50), "p10": pct(step_ms, 10), "p90": pct(step_ms, 90), "min": pct(step_ms, 0), "max": pct(step_ms, 100),

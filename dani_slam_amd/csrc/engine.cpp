@@ -110,15 +110,16 @@ std::unordered_map<hipStream_t, NearMark> g_near;
 inline int wait_mode() {
   static const int env_mode = [] {
     const char* m = getenv("DANI_HOST_WAIT");
-    if (m) return !strcmp(m, "block") ? 0 : (!strcmp(m, "spin") ? 1 : 2);
-    const char* sp = getenv("DANI_SPIN_WAIT");
-    return (sp && atoi(sp) != 0) ? 1 : 2;
+    if (m) return !strcmp(m, "block") ? 0 : (!strcmp(m, "hybrid") ? 2 : 1);
+    return 1;   // spin: what the runtime's own wait costs in CPU on this ROCm build, without its wake-up outliers (engine_internal.h)
   }();
   const int mode = g_host_wait.load(std::memory_order_relaxed);
   return mode < 0 ? env_mode : mode;
 }
 inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
+
+int wait_mode_now() { return wait_mode(); }
 
 void near_mark(hipStream_t s) {
   if (wait_mode() != 2) return;
@@ -198,6 +199,8 @@ int dani_set_host_wait(int32_t mode) {
   dani::eng::g_host_wait.store(mode, std::memory_order_relaxed);
   return DANI_OK;
 }
+
+int dani_get_host_wait(void) { return dani::eng::wait_mode_now(); }
 
 const char* dani_version(void) { return "dani-frontend-hip 0.1 (gfx950)"; }
 

@@ -26,17 +26,22 @@ namespace eng {
 
 extern thread_local std::string g_create_error;
 
-// Every stream wait of the engine goes through here (engine.cpp).  dani_set_host_wait / DANI_HOST_WAIT:
-//   0 "block"   hipStreamSynchronize.  On this ROCm build that is NOT a sleep: the runtime busy-waits (measured with per-thread CPU
-//               clocks in bench.py: 10.8 ms of caller CPU + 9.9 ms of a runtime thread per 10.8 ms front-end call)
-//   1 "spin"    poll hipStreamQuery from user space: same cost, 0.05 ms per call faster than the runtime's own wait
-//   2 "hybrid"  (default) two stages: SLEEP (40 us naps polling an event) until a marker that the engine records a few hundred
-//               microseconds of GPU work ahead of the point it is going to wait for (near_mark below: behind SuperPoint's detector
-//               head, in front of LightGlue's last FFN), then SPIN for the rest.  Waits without a marker spin for at most 150 us
-//               and then hand over to hipStreamSynchronize.  Same throughput as the other two on the same box (745 / 743 / 746
-//               frames/s), caller CPU 2.1 ms and runtime thread 4.7 ms per 10.7 ms call: one core instead of 2.3
-//               (profiles/r04_bench_host_wait_*.json).
-extern std::atomic<int> g_host_wait;   // -1 = the environment's choice (DANI_HOST_WAIT=block|spin|hybrid, DANI_SPIN_WAIT=1; default hybrid)
+// Every stream wait of the engine goes through here (engine.cpp).  dani_set_host_wait / DANI_HOST_WAIT, measured with per-thread
+// CPU clocks on the 8-frame front-end call (bench.py: host_cpu_ms_per_step_top_threads; profiles/r04_bench_host_wait_*.json,
+// r04_bench_final.json):
+//   0 "block"   hipStreamSynchronize.  On this ROCm build that is NOT a sleep that frees the core: 10.8 ms of caller CPU + 9.9 ms
+//               of a runtime thread per 10.8 ms call -- and it still yields the core now and then: on a loaded host 5 % of the
+//               calls come back 3-4 ms late (one scheduler tick).
+//   1 "spin"    (default) poll hipStreamQuery from user space: the same CPU (10.7 + 9.9 ms), 0.03-0.05 ms per call faster on a
+//               quiet host and free of the late wake-ups on a loaded one (mean 10.76 against 10.94 ms on the same box).
+//   2 "hybrid"  two stages: SLEEP (40 us naps polling an event) until a marker that the engine records a few hundred microseconds
+//               of GPU work ahead of the point it is going to wait for (near_mark below: behind SuperPoint's detector head, in
+//               front of LightGlue's last FFN), then SPIN for the rest; waits without a marker spin for at most 150 us and then
+//               hand over to hipStreamSynchronize.  2.1 + 4.7 ms of CPU per call -- one core instead of 2.3 -- and the median of
+//               the other two, but a thread that sleeps can be scheduled late: the same 3-4 ms outliers as mode 0 on a loaded host.
+//               For deployments that need the core more than the last per cent.
+extern std::atomic<int> g_host_wait;   // -1 = the environment's choice (DANI_HOST_WAIT=block|spin|hybrid; default spin)
+int wait_mode_now();                   // the mode in force
 hipError_t stream_wait(hipStream_t s, void (*before_spin)(void*) = nullptr, void* arg = nullptr);   // before_spin: called once when the naps are over (or at once without a marker / in the pure modes)
 void near_mark(hipStream_t s);     // "the next wait on s is a few hundred microseconds of GPU work away": records s's marker event
 void near_forget(hipStream_t s);   // the stream is about to be destroyed

@@ -336,23 +336,28 @@ __global__ __launch_bounds__(1024) void ln_gelu_kernel(float* hbuf, const float*
   }
 }
 
-// Small token counts (one or two pairs: 33-66 of the 64-token workgroups above on 256 CUs): 16 tokens per workgroup.  Lane =
-// (token l & 15, feature quarter l >> 4), wave g holds features [32g + 8q, 32g + 8q + 8) of its 16 tokens in 8 VGPRs; the
-// statistics are reduced over the 4 quarters by two shuffles and over the 16 waves through LDS.  Same arithmetic per element;
-// the order of the two reductions differs from ln_gelu_kernel's (LightGlue is held to 1e-3).
-__global__ __launch_bounds__(1024) void ln_gelu16_kernel(float* hbuf, const float* gamma, const float* beta, int T, int ld) {
-  __shared__ float red[16][16];
-  const int l = threadIdx.x & 63, tl = l & 15, q = l >> 4, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tok = blockIdx.x * 16 + tl;
+// TOK = 16 or 32 tokens per workgroup instead of 64.  Lane = (token l % TOK, feature group l / TOK), wave g holds features
+// [32g + R q, 32g + R q + R) of its TOK tokens in R = 32 TOK / 64 VGPRs; the statistics are reduced over the 64 / TOK groups by
+// shuffles and over the 16 waves through LDS.  Same arithmetic per element; the order of the two reductions differs from
+// ln_gelu_kernel's (LightGlue is held to 1e-3).  16: small token counts (one or two pairs are 33-66 of the 64-token workgroups on
+// 256 CUs).  32: the large batches -- a 64-token workgroup runs load -> reduce -> erf -> store in lock step, and 257 of them on 256
+// CUs leave nothing to overlap those phases with; 513 workgroups put two on every CU.
+template <int TOK>
+__global__ __launch_bounds__(1024) void ln_gelu_tok_kernel(float* hbuf, const float* gamma, const float* beta, int T, int ld) {
+  constexpr int NQ = 64 / TOK, R = 32 / NQ;
+  __shared__ float red[16][TOK];
+  const int l = threadIdx.x & 63, tl = l & (TOK - 1), q = l / TOK, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tok = blockIdx.x * TOK + tl;
   const bool ok = tok < T;
-  float v[8];
+  float v[R];
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    v[i] = ok ? (hbuf + (size_t)(g * 32 + q * 8 + i) * ld)[tok] : 0.0f;
+  for (int i = 0; i < R; i++) {
+    v[i] = ok ? (hbuf + (size_t)(g * 32 + q * R + i) * ld)[tok] : 0.0f;
     s += v[i];
   }
-  s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+#pragma unroll
+  for (int o = TOK; o < 64; o <<= 1) s += __shfl_xor(s, o);
   if (q == 0) red[g][tl] = s;
   __syncthreads();
   float tot = 0.0f;
@@ -362,8 +367,9 @@ __global__ __launch_bounds__(1024) void ln_gelu16_kernel(float* hbuf, const floa
   __syncthreads();
   float s2 = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { const float d = v[i] - mean; s2 += d * d; }
-  s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+  for (int i = 0; i < R; i++) { const float d = v[i] - mean; s2 += d * d; }
+#pragma unroll
+  for (int o = TOK; o < 64; o <<= 1) s2 += __shfl_xor(s2, o);
   if (q == 0) red[g][tl] = s2;
   __syncthreads();
   float tv = 0.0f;
@@ -372,8 +378,8 @@ __global__ __launch_bounds__(1024) void ln_gelu16_kernel(float* hbuf, const floa
   const float rstd = 1.0f / sqrtf(tv * (1.0f / 512.0f) + 1e-5f);
   if (!ok) return;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int f = g * 32 + q * 8 + i;
+  for (int i = 0; i < R; i++) {
+    const int f = g * 32 + q * R + i;
     const float y = (v[i] - mean) * rstd * gamma[f] + beta[f];
     (hbuf + (size_t)f * ld)[tok] = 0.5f * y * (1.0f + lg_erff(y * 0.70710678118654752440f));
   }
@@ -381,7 +387,10 @@ __global__ __launch_bounds__(1024) void ln_gelu16_kernel(float* hbuf, const floa
 
 void launch_ln_gelu(float* hbuf, const float* gamma, const float* beta, int T, int ld, hipStream_t s) {
   static const int small_t = getenv("DANI_LN_SMALL_T") ? atoi(getenv("DANI_LN_SMALL_T")) : 64 * 128;   // fewer than 128 of the 64-token workgroups
-  if (T < small_t) hipLaunchKernelGGL(ln_gelu16_kernel, dim3((T + 15) / 16), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
+  static const int big_tok = getenv("DANI_LN_TOK") ? atoi(getenv("DANI_LN_TOK")) : 32;                 // tokens per workgroup for the large batches (32 or 64)
+  if (T < small_t) hipLaunchKernelGGL(ln_gelu_tok_kernel<16>, dim3((T + 15) / 16), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
+  else if (big_tok == 32) hipLaunchKernelGGL(ln_gelu_tok_kernel<32>, dim3((T + 31) / 32), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
+  else if (big_tok == 16) hipLaunchKernelGGL(ln_gelu_tok_kernel<16>, dim3((T + 15) / 16), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
   else hipLaunchKernelGGL(ln_gelu_kernel, dim3((T + 63) / 64), dim3(1024), 0, s, hbuf, gamma, beta, T, ld);
 }
 

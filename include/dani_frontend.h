@@ -169,12 +169,15 @@ DANI_API int dani_lg_set_gemm(dani_engine* e, int32_t mode);
  * Returns DANI_ERR_INVALID for an unknown name or any other value (the probe-only kernels are not selectable here). */
 DANI_API int dani_lg_set_kernel_option(const char* name, int32_t value);
 /* How the calling thread waits for the GPU inside every entry point, process-wide (environment: DANI_HOST_WAIT=block|spin|hybrid):
- *   0 = hipStreamSynchronize (which busy-waits on this ROCm build: one core for the caller and most of one for a runtime thread);
- *   1 = spin on hipStreamQuery (the same cost, 0.05 ms per 8-frame call faster);
- *   2 = hybrid (default): sleep in 40 us naps until a marker event the engine records a few hundred microseconds of GPU work ahead
- *       of the point it will wait for, then spin for the rest; waits without a marker spin for at most 150 us, then use mode 0.
- *       Same throughput, ~1 core instead of ~2.3 per calling thread (bench.py: host_cpu_ms_per_step). */
+ *   0 = hipStreamSynchronize (which busy-waits on this ROCm build -- one core for the caller and most of one for a runtime thread --
+ *       and still comes back a scheduler tick late now and then on a loaded host);
+ *   1 = spin on hipStreamQuery (default: the same CPU cost, no late wake-ups);
+ *   2 = hybrid: sleep in 40 us naps until a marker event the engine records a few hundred microseconds of GPU work ahead of the
+ *       point it will wait for, then spin for the rest; waits without a marker spin for at most 150 us, then use mode 0.  About one
+ *       core instead of 2.3 per calling thread at the same median latency; a sleeping thread can be scheduled late.
+ * dani_get_host_wait returns the mode in force. */
 DANI_API int dani_set_host_wait(int32_t mode);
+DANI_API int dani_get_host_wait(void);
 
 /* Replaces LightGlue::matchDescriptors + normalizeKeypoints + filterMatches (src/LightGlue.cpp:18-122), as
  * called from Frame::ComputeStereoMatches (src/Frame.cc:860), LGmatcher::SearchByBoW (src/LGmatcher.cpp:314) and

@@ -128,7 +128,8 @@ def test_process_wide_options_validate_their_arguments():
     assert lib.dani_lg_set_kernel_option(b"lin_rs", -1) == 0 and lib.dani_lg_set_kernel_option(b"attn", 0) == 0 and lib.dani_lg_set_kernel_option(b"ffn_chain", -1) == 0   # the defaults
     assert lib.dani_set_host_wait(7) == frontend.DANI_ERR_INVALID
     assert lib.dani_set_host_wait(-1) == frontend.DANI_ERR_INVALID and lib.dani_set_host_wait(3) == frontend.DANI_ERR_INVALID
-    assert lib.dani_set_host_wait(1) == 0 and lib.dani_set_host_wait(0) == 0 and lib.dani_set_host_wait(2) == 0   # block, spin, hybrid (the default)
+    assert lib.dani_set_host_wait(0) == 0 and lib.dani_get_host_wait() == 0 and lib.dani_set_host_wait(2) == 0 and lib.dani_get_host_wait() == 2
+    assert lib.dani_set_host_wait(1) == 0 and lib.dani_get_host_wait() == 1   # block, hybrid, spin (the default)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
