@@ -231,9 +231,9 @@ void launch_posenc(const LgSet* sets, int nsets, int max_span, const float* wr, 
 void launch_desc_to_fm(const LgSet* sets, int nsets, int max_span, float* x, int ld, hipStream_t s);
 void launch_attention(const float* Q, const float* K, const float* V, float* O, int ld, const LgSet* sets, int nsets,
                       int max_mp, int max_tail, int cross, float scale, hipStream_t s, int x3 = 0);   // x3: attn_x3_kernel (bf16x3 split contractions)
-void launch_lg_densify(const float* md, const float* logsig, const LgSet* sets, int nsets, int max_n, float* md_dense,
-                       float* logsig_dense, int ld, hipStream_t s);
-void launch_matchability(const float* x, const float* w, float b, float* logsig, int T, int ld, hipStream_t s);
+// matchability logit -> logsigmoid and the dense copy of md (set s at [dense_off, dense_off + n)) in one launch
+void launch_match_densify(const float* x, const float* w, float b, const float* md, const LgSet* sets, int nsets, int max_n, float* md_dense,
+                          float* logsig_dense, int ld, hipStream_t s);
 void launch_sim(const float* md, int ld, const LgSet* sets, int npairs, int max_np, float* sim, int sim_ld,
                 size_t sim_pair_stride, hipStream_t s);
 void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const LgSet* sets, int npairs, int max_n,

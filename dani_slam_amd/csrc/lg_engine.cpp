@@ -339,9 +339,8 @@ bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
     else { near_mark(s); ffn_and_next(C, W->final_proj, L->md, 0, 0.25f); }   // / d^0.25, d = 256; the caller's final wait is one FFN + the match head away
   }
   L->lin_launches = li / 2;
-  launch_matchability(L->x, W->match_w, W->match_b, L->logsig, T, ld, s);
   const size_t pstride = (size_t)(round_up(L->kmax, 32) + 64) * L->sim_ld;
-  launch_lg_densify(L->md, L->logsig, L->d_sets, nsets, max_n, L->md_dense, L->logsig_dense, ld, s);
+  launch_match_densify(L->x, W->match_w, W->match_b, L->md, L->d_sets, nsets, max_n, L->md_dense, L->logsig_dense, ld, s);
   launch_sim(L->md_dense, ld, L->d_sets, nsets / 2, max_np, L->sim, L->sim_ld, pstride, s);
   launch_assignment_stats(L->sim, L->sim_ld, pstride, L->d_sets, nsets / 2, max_n, L->logsig_dense, L->lse_row, L->lse_col,
                           L->m0, L->max0, L->m1, ld, s);

@@ -1498,31 +1498,40 @@ void launch_attention(const float* Q, const float* K, const float* V, float* O, 
 // MatchAssignment: matchability logit -> logsigmoid;  sim = md0^T md1 per pair;  log-double-softmax statistics;
 // row / column argmax of  scores = log_softmax_row(sim) + log_softmax_col(sim) + logsig(z0) + logsig(z1).
 // ---------------------------------------------------------------------------------------------
-__global__ void matchability_kernel(const float* x, const float* w, float b, float* logsig, int T, int ld) {
-  const int tok = blockIdx.x * 64 + threadIdx.x;
-  if (tok >= T) return;
-  float z = b;
-  for (int f = 0; f < 256; f++) z += w[f] * x[(size_t)f * ld + tok];
-  logsig[tok] = -(fmaxf(-z, 0.0f) + log1pf(__expf(-fabsf(z))));
+// The matchability term and the dense copy in one pass (rounds 1-3: a thread per token walking 256 rows alone, 21.7 us, then 70 000
+// workgroups of 64 threads copying one row segment each, 18.4 us).  The assignment stage works on a dense copy of the projected
+// descriptors and matchability terms: set s occupies [dense_off, dense_off + n) (padded to 32), gathered from its main region
+// and its tail tokens.  Workgroup = 64 tokens of one set x 8 feature groups of 32: each thread copies its 32 rows of md and
+// accumulates its share of z = b + w . x; the eight partial sums meet in LDS in group order.
+__global__ __launch_bounds__(512) void match_densify_kernel(const float* x, const float* w, float b, const float* md, const LgSet* sets,
+                                                            float* md_dense, float* logsig_dense, int ld) {
+  __shared__ float part[8][64];
+  const LgSet st = sets[blockIdx.y];
+  const int tl = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = blockIdx.x * 64 + tl;
+  const bool ok = i < st.n;
+  const int tok = !ok ? 0 : (i < st.nmain ? st.tok_off + i : st.tail_off + (i - st.nmain));
+  const int dpos = st.dense_off + i;
+  float z = 0.0f;
+#pragma unroll 8
+  for (int k = 0; k < 32; k++) {
+    const int f = g * 32 + k;
+    const float xv = ok ? x[(size_t)f * ld + tok] : 0.0f;
+    if (ok) md_dense[(size_t)f * ld + dpos] = md[(size_t)f * ld + tok];
+    z = __builtin_fmaf(w[f], xv, z);
+  }
+  part[g][tl] = z;
+  __syncthreads();
+  if (g == 0 && ok) {
+    float zz = b;
+#pragma unroll
+    for (int k = 0; k < 8; k++) zz += part[k][tl];
+    logsig_dense[dpos] = -(fmaxf(-zz, 0.0f) + log1pf(__expf(-fabsf(zz))));
+  }
 }
-void launch_matchability(const float* x, const float* w, float b, float* logsig, int T, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(matchability_kernel, dim3((T + 63) / 64), dim3(64), 0, s, x, w, b, logsig, T, ld);
-}
-
-// The assignment stage works on a dense copy of the projected descriptors and matchability terms: set s occupies
-// [dense_off, dense_off + n) (padded to 32), gathered from its main region and its tail tokens.
-__global__ __launch_bounds__(64) void lg_densify_kernel(const float* md, const float* logsig, const LgSet* sets, float* md_dense,
-                                                        float* logsig_dense, int ld) {
-  const LgSet st = sets[blockIdx.z];
-  const int i = blockIdx.x * 64 + threadIdx.x, f = blockIdx.y;
-  if (i >= st.n) return;
-  const int tok = i < st.nmain ? st.tok_off + i : st.tail_off + (i - st.nmain);
-  if (f < 256) md_dense[(size_t)f * ld + st.dense_off + i] = md[(size_t)f * ld + tok];
-  else logsig_dense[st.dense_off + i] = logsig[tok];
-}
-void launch_lg_densify(const float* md, const float* logsig, const LgSet* sets, int nsets, int max_n, float* md_dense,
-                       float* logsig_dense, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(lg_densify_kernel, dim3((max_n + 63) / 64, 257, nsets), dim3(64), 0, s, md, logsig, sets, md_dense, logsig_dense, ld);
+void launch_match_densify(const float* x, const float* w, float b, const float* md, const LgSet* sets, int nsets, int max_n, float* md_dense,
+                          float* logsig_dense, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(match_densify_kernel, dim3((max_n + 63) / 64, nsets), dim3(512), 0, s, x, w, b, md, sets, md_dense, logsig_dense, ld);
 }
 
 // sim[pair][i][j] = sum_d md[d][off0+i] * md[d][off1+j]; tile 64 (i) x 128 (j): wave w -> j block pair? 4 waves = 2x2 of 32x64
@@ -1541,6 +1550,9 @@ __global__ __launch_bounds__(256, 2) void sim_kernel(const float* md, int ld, co
   f32x16 acc[2];
 #pragma unroll
   for (int r = 0; r < 16; r++) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+  // (chunk k0 + 32 prefetched into registers under chunk k0's MFMAs was measured and changed nothing: 55.0 against 56.1 us -- two
+  //  workgroups per CU already cover each other's loads; the launch is 2.4 rounds of 512 resident workgroups with 11 % of the tile
+  //  area past the sets' ends)
   for (int k0 = 0; k0 < 256; k0 += 32) {
     __syncthreads();
     // A: 32 x 64 floats = 512 float4 (2/thread); B: 32 x 128 = 1024 float4 (4/thread)
