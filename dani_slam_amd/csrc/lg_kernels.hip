@@ -1684,6 +1684,9 @@ void launch_assignment_stats(const float* sim, int sim_ld, size_t pstride, const
   if (((max_n + 63) / 64) * npairs < 64)
     hipLaunchKernelGGL((col_stats_kernel<16, 64>), dim3((max_n + 15) / 16, npairs), dim3(1024), 0, s, sim, sim_ld, pstride, sets, lse_row,
                        logsig, lse_col, m1, ld);
+  else if (((max_n + 63) / 64) * npairs < 256)   // 8 pairs of ~1026 keypoints: 136 workgroups of the 64-column form for 256 CUs; 32 columns x 32 row groups: 264
+    hipLaunchKernelGGL((col_stats_kernel<32, 32>), dim3((max_n + 31) / 32, npairs), dim3(1024), 0, s, sim, sim_ld, pstride, sets, lse_row,
+                       logsig, lse_col, m1, ld);
   else
     hipLaunchKernelGGL((col_stats_kernel<64, 16>), dim3((max_n + 63) / 64, npairs), dim3(1024), 0, s, sim, sim_ld, pstride, sets, lse_row,
                        logsig, lse_col, m1, ld);
