@@ -218,3 +218,47 @@ def test_yolov5s_batchnorm_is_fused_on_the_host(tmp_path, sp_weights):
     cw.write_dsw(str(tmp_path / "half.dsw"), some)
     rc, _, msg = check_file(tmp_path / "half.dsw")
     assert rc == frontend.DANI_ERR_WEIGHTS and "missing tensor model.24.m.2.weight [255,512,1,1] (YOLOv5s" in msg
+
+
+def test_damaged_containers_are_error_codes_not_crashes(tmp_path, sp_weights):
+    """dani_check_weights_file on 300 damaged copies of a valid .dsw -- truncated at every kind of boundary, name lengths and
+    element counts overwritten with huge / zero / negative-looking values, random byte flips in the directory part -- answers with
+    a status and a message every time (the parser runs inside this process: a wild read would take pytest down with it), and
+    accepts only containers whose directory is still intact (src/SPextractor.cpp:86-91: the reference exits on a bad archive)."""
+    good = tmp_path / "good.dsw"
+    cw.write_dsw(str(good), sp_weights)
+    blob = bytearray(good.read_bytes())
+    assert check_file(good)[0] == 0
+    rng = np.random.default_rng(7)
+    first_name_len = 8                                       # "DSW1", u32 n, then the first record's u32 name length
+    cases = []
+    for cut in [0, 3, 4, 7, 8, 11, 12, 20, 21, 29, len(blob) // 2, len(blob) - 1]:
+        cases.append(bytes(blob[:cut]))
+    for v in (0, 255, 256, 0x7fffffff, 0xffffffff):
+        b = bytearray(blob); b[first_name_len:first_name_len + 4] = int(v).to_bytes(4, "little"); cases.append(bytes(b))
+    nl = int.from_bytes(blob[first_name_len:first_name_len + 4], "little")
+    cnt_at = first_name_len + 4 + nl
+    for v in (0, 1, (1 << 28) - 1, 1 << 28, (1 << 63) - 1, (1 << 64) - 1):
+        b = bytearray(blob); b[cnt_at:cnt_at + 8] = int(v).to_bytes(8, "little"); cases.append(bytes(b))
+    for v in (0, 1, 11, 13, 0xffffffff):                     # record count of the container
+        b = bytearray(blob); b[4:8] = int(v).to_bytes(4, "little"); cases.append(bytes(b))
+    n_structured = len(cases)
+    while len(cases) < 300:
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, min(len(b), 4096)))] = int(rng.integers(0, 256))
+        if rng.random() < 0.3:
+            b = b[:int(rng.integers(8, len(b)))]
+        cases.append(bytes(b))
+    rejected_random = 0
+    for i, c in enumerate(cases):
+        p = tmp_path / "bad.dsw"
+        p.write_bytes(c)
+        rc, groups, msg = check_file(p)
+        assert rc in (0, frontend.DANI_ERR_WEIGHTS), (i, rc, msg)
+        assert rc == 0 or msg, i
+        if i < n_structured:
+            assert rc == frontend.DANI_ERR_WEIGHTS, (i, msg)          # every truncation and every damaged length / count is refused
+        else:
+            rejected_random += rc != 0                                  # (a flip inside a float payload leaves a valid container)
+    assert rejected_random > 20
