@@ -252,3 +252,32 @@ def test_split_form_equals_fused_call_and_takes_a_foreign_predecessor(sp_weights
     e.frontend_finish_pending()                                                                  # nothing pending: no-op
     e.frontend_batch(gray[:4], bgr[:4], nfeatures=NF, match_previous=False, defer_desc=True, copy=False)
     e.close()                                                                                    # pending read-back cancelled
+
+
+def test_the_three_host_waits_give_the_same_results(weights):
+    """dani_set_host_wait 0 / 2 / 1 (hipStreamSynchronize, naps to the engine's near-end marker then polls, polls): the same call
+    gives byte-identical keypoints, descriptors, boxes, matches and scores in every mode, on the 8-frame engine (marker behind
+    SuperPoint's detector head and in front of LightGlue's last FFN) and on a one-frame-at-a-time engine."""
+    from dani_slam_amd import frontend
+    for mb, idx in ((8, list(range(8))), (2, [0, 1])):
+        e = frontend.Engine(device=0, max_batch=mb, weights=weights)
+        e.yolo_set_classes(yo.COCO_NAMES, yo.DYNAMIC_NAMES)
+        default_mode = e.host_wait()
+        assert default_mode == "spin"
+        gray = np.stack([synth.sequence_frame(i) for i in idx]); bgr = np.stack([synth.sequence_frame_bgr(i) for i in idx])
+        ref = None
+        try:
+            for mode in ("block", "hybrid", "spin"):
+                e.set_host_wait(mode)
+                assert e.host_wait() == mode
+                e.frontend_reset()
+                out = e.frontend_batch(gray, bgr, nfeatures=NF) + e.frontend_batch(gray, bgr, nfeatures=NF)
+                if ref is None:
+                    ref = out
+                    continue
+                for a, b in zip(ref, out):
+                    for k in ("kpts", "resp", "desc", "boxes", "matches", "scores"):
+                        assert np.array_equal(a[k], b[k]), (mode, k)
+        finally:
+            e.set_host_wait(default_mode)
+            e.close()
