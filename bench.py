@@ -549,7 +549,10 @@ def main():
                                              + ("; posted after a step's extraction and waited for one extraction later: the LightGlue of "
                                                 "step t runs behind the extraction of step t + 1" if pipelined else "; lock-step") if boundary else
                                              f"frame-sharded x{world}, no data-path collective")}
-            res["roofline"] = {"bound": "mfma", "kernel": "linear_rs_kernel<NCB,UQ> (LightGlue feature-major linear layers, register-streaming form of lin_rs.h: 6 per layer x 9 + final_proj; linear_fm_kernel<64> where its grid fills the chip better)",
+            chain_active = lin_launches != 55      # lg_forward counts an FFN block that went through ffn_chain_kernel as ONE timed interval
+            res["roofline"] = {"bound": "mfma", "kernel": "linear_rs_kernel<NCB,UQ> (LightGlue feature-major linear layers, register-streaming form of lin_rs.h: 6 per layer x 9 + final_proj; linear_fm_kernel<64> where its grid fills the chip better)"
+                                       + (" + ffn_chain_kernel (ffn.0 -> LayerNorm + GELU -> ffn.3 -> next projection as one launch per block, ffn_chain.h: taken at this batch size; "
+                                          "its LayerNorm + GELU time is inside the denominator, the numerator counts the linear layers' FLOP only)" if chain_active else ""),
                                "achieved": round(achieved, 3), "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "launches_per_step": lin_launches,
