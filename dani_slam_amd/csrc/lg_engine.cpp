@@ -482,7 +482,9 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
   }
   HIP_TRY(e, hipEventRecord(c->ev_lg1, s));
   HIP_TRY(e, hipGetLastError());
-  HIP_TRY(e, hipMemcpy2DAsync(L->h_m0, (size_t)L->ld * 4, L->m0, (size_t)L->ld * 4, (size_t)doff * 4, 3, hipMemcpyDeviceToHost, s));
+  // m0 | m1 | max0 are three rows of one block: ONE linear copy up to the end of the third row's valid part (the strided 2-D form
+  // took a slower path in the runtime and sits at the very end of the call)
+  HIP_TRY(e, hipMemcpyAsync(L->h_m0, L->m0, ((size_t)2 * L->ld + (size_t)doff) * 4, hipMemcpyDeviceToHost, s));
   if (call.overlap) (*call.overlap)();   // host work of the caller that can run under the forward pass
   HIP_TRY(e, hipStreamSynchronize(s));
   (void)hipEventElapsedTime(&c->ms[0], c->ev_lg0, c->ev_lg1);
