@@ -127,6 +127,30 @@ def test_heads_finished_in_the_conv_epilogue_bit_exact(sp_weights, oracle_frames
         e.close()
 
 
+def test_fused_heads_on_small_engines_pyramids_and_odd_sizes(sp_weights, oracle_frames, monkeypatch):
+    """DANI_SP_FUSE_HEADS=1 puts the epilogue-fused heads on engines the size rule would leave alone: a four-level pyramid (odd
+    level sizes, partial 8 x 16 cell tiles on both axes, boxes and a lapping area) on a one-frame engine, and a 328 x 248 image
+    (41 x 31 cells) -- keypoints, octaves, responses and descriptors against the oracle."""
+    from dani_slam_amd import frontend
+    monkeypatch.setenv("DANI_SP_FUSE_HEADS", "1")
+    e = frontend.Engine(device=0, max_batch=1, max_width=640, max_height=480, weights=sp_weights)
+    try:
+        assert e.sp_layer_kernel(9).endswith("+softmax_d2s") and e.sp_layer_kernel(11).endswith("+l2norm_nhwc")
+        img = oracle_frames[1][0]
+        boxes = [(200, 120, 160, 240)]
+        ref = oracle.sp_extract(img, sp_weights, nfeatures=1000, nlevels=4, boxes=boxes, lapping=(0, 300))
+        r = e.sp_extract_batch(img[None], nfeatures=1000, nlevels=4, boxes=[np.array(boxes, np.int32)], lapping=(0, 300))[0]
+        for k in ("kpts", "octave", "size", "resp", "desc"):
+            assert np.array_equal(r[k], ref[k]), k
+        assert r["mono_index"] == ref["mono_index"] and len(np.unique(ref["octave"])) == 4
+        small = synth.frame(2)[100:100 + 248, 200:200 + 328].copy()
+        ref = oracle.sp_extract(small, sp_weights, nfeatures=400)
+        r = e.sp_extract_batch(small[None], nfeatures=400)[0]
+        assert np.array_equal(r["kpts"], ref["kpts"]) and np.array_equal(r["desc"], ref["desc"])
+    finally:
+        e.close()
+
+
 def test_dense_frames_have_no_candidate_limit(sp_weights):
     """A frame on which EVERY pixel of every cell is a candidate -- a detector head with zero weights gives the flat probability
     map 1/65 = 0.0154 > iniTh = 0.015 -- i.e. 204 cells x up to 1848 pixels with the 6-px overlap strips counted twice (quirk
