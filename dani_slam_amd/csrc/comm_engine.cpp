@@ -97,6 +97,12 @@ void comm_release(dani_engine* e) {
 
 extern "C" {
 
+int dani_comm_available(void) {
+  RcclApi* api = rccl_api();
+  if (!api->lib) return fail(nullptr, DANI_ERR_UNSUPPORTED, "librccl could not be loaded: %s", api->err.c_str());
+  return DANI_OK;
+}
+
 int dani_comm_unique_id(void* id, int32_t id_bytes) {
   if (!id || id_bytes < DANI_COMM_ID_BYTES) return DANI_ERR_INVALID;
   RcclApi* api = rccl_api();

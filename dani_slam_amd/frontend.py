@@ -126,6 +126,7 @@ def load_library():
     lib.dani_frontend_export_features.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, _i32]
     lib.dani_frontend_match_resident.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_float, _i32, _f, C.c_int32, _i32]
     lib.dani_frontend_timings.argtypes = [C.c_void_p, _f]
+    lib.dani_comm_available.argtypes = []
     lib.dani_comm_unique_id.argtypes = [C.c_void_p, C.c_int32]
     lib.dani_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.dani_comm_destroy.argtypes = [C.c_void_p]
@@ -603,6 +604,11 @@ class Engine:
 
     # -- the sharded batch's collective, native (RCCL all-gather behind the C ABI; include/dani_frontend.h) -------------
     COMM_ID_BYTES = 128
+
+    @staticmethod
+    def comm_available() -> bool:
+        """True when librccl loads with every symbol the engine uses (dani_comm_available); no communicator, no id."""
+        return load_library().dani_comm_available() == 0
 
     @staticmethod
     def comm_unique_id() -> bytes:

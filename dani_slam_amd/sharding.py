@@ -150,12 +150,28 @@ class NativeExchange:
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
+            # Every step below that can fail on ONE rank is followed by an agreement before anybody enters a collective that the
+            # failed rank would never join (a rank waiting alone in a broadcast or in ncclCommInitRank hangs the whole job).
+            uid, err = None, None
+            try:
+                if not eng.comm_available():        # every rank: does librccl load here?
+                    raise RuntimeError("librccl could not be loaded")
+                if rank == 0:
+                    uid = eng.comm_unique_id()
+            except Exception as ex:                 # noqa: BLE001 -- reported below, on every rank
+                err = f"rank {rank}: {ex}"
             if world > 1:
-                box = [eng.comm_unique_id() if rank == 0 else None]
+                import torch
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+                okf = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                if int(okf.item()) == 0:
+                    raise RuntimeError(err or "librccl could not be loaded on another rank")
+                box = [uid if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 uid = box[0]
-            else:
-                uid = eng.comm_unique_id()
+            elif err:
+                raise RuntimeError(err)
             eng.comm_create(uid, rank, world)
         finally:
             os.dup2(saved, 1)

@@ -339,6 +339,7 @@ DANI_API int dani_frontend_match_resident(dani_engine* e, int32_t sequence, cons
  * Nothing is synchronised with the host between the three calls: the collective and its consumer are ordered by the sequence's
  * stream.  librccl is loaded (dlopen) when the first id / communicator is created; DANI_ERR_UNSUPPORTED if it cannot be. */
 #define DANI_COMM_ID_BYTES 128
+DANI_API int dani_comm_available(void);                                          /* DANI_OK when librccl loads with every symbol the engine uses (no communicator, no id): lets every rank check BEFORE the collective calls below */
 DANI_API int dani_comm_unique_id(void* id, int32_t id_bytes);                    /* ncclGetUniqueId; id_bytes >= DANI_COMM_ID_BYTES */
 DANI_API int dani_comm_create(dani_engine* e, const void* id, int32_t id_bytes, int32_t rank, int32_t world);   /* ncclCommInitRank on the engine's GPU */
 DANI_API int dani_comm_destroy(dani_engine* e);                                  /* also done by dani_engine_destroy */
