@@ -84,3 +84,44 @@ def test_world2_gloo_allgather_and_max():
     assert all(r[1] for r in res)
     assert all(abs(r[2] - 2.0) < 1e-12 for r in res)                 # max over ranks of (1.0, 2.0)
     assert res[0][3] + res[1][3] == list(range(16))
+
+
+def _native_worker(rank, world, port, q, broken_rank):
+    """NativeExchange's construction with a stand-in engine: on `broken_rank` librccl "does not load"."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        class FakeEngine:
+            def comm_available(self): return rank != broken_rank
+            def comm_unique_id(self): calls.append("id"); return bytes(range(128))
+            def comm_create(self, uid, r, w): calls.append(("create", bytes(uid), r, w))
+        try:
+            sharding.NativeExchange(FakeEngine(), 16, rank, world)
+            outcome = "built"
+        except RuntimeError as ex:
+            outcome = "refused: " + str(ex)
+        q.put((rank, outcome, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("broken_rank", [-1, 0, 1])
+def test_native_exchange_construction_never_leaves_a_rank_alone_in_a_collective(broken_rank):
+    """World size 2 over gloo: when librccl loads everywhere, rank 0's id reaches rank 1 and both call comm_create with it; when it
+    does not load on ONE rank (either one), BOTH ranks give up before the id broadcast / ncclCommInitRank -- nobody hangs."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_native_worker, args=(r, world, port, q, broken_rank)) for r in range(world)]
+    for p in ps: p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps: p.join(timeout=60)
+    if broken_rank < 0:
+        assert [r[1] for r in res] == ["built", "built"]
+        assert res[0][2] == ["id", ("create", bytes(range(128)), 0, 2)] and res[1][2] == [("create", bytes(range(128)), 1, 2)]
+    else:
+        assert all(r[1].startswith("refused") for r in res), res
+        assert all(not any(isinstance(c, tuple) for c in r[2]) for r in res)      # comm_create was never reached
