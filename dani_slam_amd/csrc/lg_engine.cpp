@@ -301,8 +301,10 @@ bool lg_forward(const LgWeights* W, LgContext* L, const LgShape& sh, hipStream_t
     const bool have = W->self_[0].ffn0.pc && W->self_[0].ffn3.pc && W->cross_[0].a.pc && W->self_[0].a.pc && W->final_proj.pc;
     auto rounds = [](int nb) { return (nb + 1023) / 1024; };
     const bool all_in = rounds(nb_all) == rounds(nb_main);      // the tail region fits the last round: no launches of its own
-    const double chain_us = rounds(all_in ? nb_all : nb_main) * 160.0 + (all_in ? 0.0 : 33.0), four_us = (double)T / 16416.0 * 181.0;
-    const bool pays = nb_main >= 768 && chain_us < four_us - 5.0;
+    // (re-measured on the final code: 16 frames per call = 2 rounds + tail is 0.05 ms per step SLOWER with the chain, 32 frames =
+    //  4 rounds + tail 0.4 ms faster, 64 frames 1.3 ms faster: the tail's price and the margin below are set to that)
+    const double chain_us = rounds(all_in ? nb_all : nb_main) * 160.0 + (all_in ? 0.0 : 40.0), four_us = (double)T / 16416.0 * 181.0;
+    const bool pays = nb_main >= 768 && chain_us < four_us - 10.0;
     if (gemm == DANI_LG_GEMM_F32 && have && force != 0 && (force == 1 || pays)) chain_blocks = all_in ? nb_all : nb_main;
   }
   const int T_rest = T - 16 * chain_blocks;                 // tokens of the tail region that keep the four-launch path
