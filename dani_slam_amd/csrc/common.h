@@ -246,7 +246,7 @@ void launch_yolo_preproc(const uint8_t* bgr, int B, int sw, int sh, int sstride,
 void launch_sppf_pool(float* cat, int C, int H, int W, int Hp, int Wp, size_t fs, int B, hipStream_t s);
 void launch_upsample2(const float* src, int sHp, int sWp, size_t sfs, float* dst, int C, int Hd, int Wd, int dHp, int dWp,
                       size_t dfs, int B, hipStream_t s);
-void launch_yolo_decode(const ActDesc* raws[3], float score_thresh, float* cand, int* cand_count, int cand_cap, int B,
+void launch_yolo_decode(const ActDesc* raws[3], float score_thresh, float* cand, float* cand_fast, int fast_cap, int* cand_count, int cand_cap, int B,
                         hipStream_t s);
 // host: greedy class-agnostic NMS of the reference (src/YoloDetect.cpp:95-144) on candidate records of 8 floats
 int yolo_nms_host(const float* cand8, int n, float iou_thresh, float* dets6, int cap);

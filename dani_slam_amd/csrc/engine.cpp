@@ -14,6 +14,7 @@ namespace dani {
 namespace eng {
 
 std::atomic<int> g_host_wait{-1};
+thread_local HostTrace t_trace;
 thread_local std::string g_create_error;
 // Error text is kept per calling thread (several host threads share one engine: stereo extractors, mapping threads):
 // the message of this thread's last failed call, tagged with the engine it belongs to; e->err (under err_mu) keeps the

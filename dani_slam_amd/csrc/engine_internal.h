@@ -167,6 +167,34 @@ namespace eng {
 
 int fail(dani_engine* e, int code, const char* fmt, ...);
 
+// Host timeline of one front-end call (DANI_TRACE_HOST=1, tools/debug/host_trace.py): labels with the microseconds since the call's
+// start, printed to stderr as one line when the call ends.  Off: one predictable branch per mark.
+struct HostTrace {
+  bool on = false;
+  std::chrono::steady_clock::time_point t0;
+  int n = 0;
+  const char* label[40];
+  float us[40];
+};
+extern thread_local HostTrace t_trace;
+inline void trace_begin() {
+  static const bool env_on = getenv("DANI_TRACE_HOST") && atoi(getenv("DANI_TRACE_HOST")) != 0;
+  t_trace.on = env_on;
+  if (env_on) { t_trace.t0 = std::chrono::steady_clock::now(); t_trace.n = 0; }
+}
+inline void trace_mark(const char* label) {
+  if (!t_trace.on || t_trace.n >= 40) return;
+  t_trace.label[t_trace.n] = label;
+  t_trace.us[t_trace.n++] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t_trace.t0).count();
+}
+inline void trace_end() {
+  if (!t_trace.on) return;
+  fprintf(stderr, "dani-trace:");
+  for (int i = 0; i < t_trace.n; i++) fprintf(stderr, " %s=%.1f", t_trace.label[i], t_trace.us[i]);
+  fprintf(stderr, "\n");
+  t_trace.on = false;
+}
+
 #define HIP_TRY(e, call)                                                                            \
   do {                                                                                              \
     hipError_t _st = (call);                                                                        \
@@ -272,6 +300,8 @@ struct SpCall {
                                       // speculatively without boxes, while the YOLO chain is still running
   bool keep_desc_on_device = false;   // `desc` may be null: descriptors are consumed on the device (LightGlue)
   bool defer_desc_sync = false;       // descriptor read-back into pinned staging on stream2, no final synchronise
+  bool defer_desc_copies = false;     // ... and the copies themselves are enqueued by the caller (sp_enqueue_desc_readback) once it has
+                                      // enqueued what comes next: eight hipMemcpyAsync calls are 29 us of host time with the GPU idle
   hipEvent_t wait_event = nullptr;    // the conv layers from index wait_layer on wait for this event (recorded on another stream)
   int wait_layer = 1;
   int reserve_lds_bytes = 0;          // fused call with YOLO on the second stream: unused dynamic LDS added to the conv layers in
@@ -280,6 +310,7 @@ struct SpCall {
   bool host_cull = false;             // single-level calls: candidate NMS + read-back are enqueued in phase 1, without the
                                       // boxes; the dynamic-box cull (exact and idempotent at scale 1) runs on the host in phase 2
 };
+int sp_enqueue_desc_readback(dani_engine* e, Context* c, const int32_t* n_out, int B);   // the fused call's descriptor read-back (stream2, behind ev_desc)
 struct YoloCall {
   Context* ctx = nullptr;
   bool alt_stream = false;            // run on the context's second (high-priority) stream, next to the SuperPoint network

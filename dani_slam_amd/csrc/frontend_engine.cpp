@@ -168,6 +168,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   }
   Context* c = S->ctx;
   t_last_seq = S;
+  trace_begin();
   const auto t0 = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - a).count(); };
 
@@ -196,6 +197,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
                            octave.data(), size.data(), desc, cap, n_out, mono_index);
   };
   if (!head_first && (rc = enqueue_sp_network())) return rc;
+  trace_mark("sp_enqueued");
 
   // ---- 1. YOLO -> dynamic boxes (Tracking.cc:1535-1539)
   std::vector<int32_t> boxes, offs(B + 1, 0);
@@ -236,6 +238,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     rc = yolo_detect_impl(e, yolo_call, bgr, on_device, B, W, H, bgr_stride, p->yolo_score_thresh, p->yolo_iou_thresh, dets.data(), dcap, nd.data());
     if (rc) return rc;
     if (mid_rc) return mid_rc;
+    trace_mark("yolo_returned");
     for (int b = 0; b < B; b++) {
       const int k = kk[b];
       n_boxes[b] = k;
@@ -248,15 +251,20 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     for (int b = 0; b < B; b++) n_boxes[b] = 0;
   }
   S->ms[0] = ms_since(t0);
+  trace_mark("boxes_done");
 
   // ---- 2. SuperPoint with the boxes as mvDynamicArea; descriptors stay resident for LightGlue
   const auto t1 = std::chrono::steady_clock::now();
   sp_call.phase = 2; sp_call.defer_desc_sync = true;
+  // the read-back's eight copies are enqueued from move_desc, i.e. behind LightGlue's launches when there is a LightGlue pass
+  static const bool old_order = getenv("DANI_FE_OLD_ORDER") && atoi(getenv("DANI_FE_OLD_ORDER")) != 0;   // A/B: rounds 1-3's order
+  sp_call.defer_desc_copies = desc != nullptr && !old_order;
   rc = sp_extract_impl(e, sp_call, gray, on_device, B, W, H, gray_stride, &p->sp, boxes.empty() ? nullptr : boxes.data(),
                        boxes.empty() ? nullptr : offs.data(), p->lapping, kpts_xy, resp, octave.data(), size.data(),
                        desc, cap, n_out, mono_index);
   if (rc) return rc;
   S->ms[1] = ms_since(t1);
+  trace_mark("phase2_done");
 
   // ---- 3. LightGlue: frame b-1 (query) vs frame b (train); slot 0 of the feature slabs = previous call's last frame
   const auto t2 = std::chrono::steady_clock::now();
@@ -271,8 +279,15 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
     (void)hipMemcpyAsync(c->d_kimg_all, c->d_kimg + (size_t)(B - 1) * c->kcap * 2, (size_t)c->kcap * 2 * 4, hipMemcpyDeviceToDevice, c->stream);
     (void)hipMemcpyAsync(c->d_desc_all, c->d_descout + (size_t)(B - 1) * c->kcap * 256, (size_t)c->kcap * 256 * 4, hipMemcpyDeviceToDevice, c->stream);
   };
+  bool copies_enqueued = false;
+  auto enqueue_desc_copies = [&] {
+    if (copies_enqueued || !desc) return;
+    copies_enqueued = true;
+    (void)sp_enqueue_desc_readback(e, c, n_out, B);   // a failure surfaces at the stream2 synchronise below / at the call's end
+  };
   std::function<void()> move_desc = [&] {
     enqueue_cache();           // behind the LightGlue kernels in stream order, ahead of the call's final synchronise
+    enqueue_desc_copies();
     if (desc_moved || !desc) return;
     desc_moved = true;
     if (hipStreamSynchronize(c->stream2) != hipSuccess) return;
@@ -310,7 +325,7 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   }
   const bool synced = cache_enqueued;   // LightGlue ran: its final synchronise covered the cache copies
   const bool defer = p->defer_desc && !p->match_previous && desc;   // split form: dani_frontend_match_resident finishes the read-back
-  if (defer) { enqueue_cache(); desc_moved = true; }
+  if (defer) { enqueue_cache(); enqueue_desc_copies(); desc_moved = true; }
   move_desc();
   if (!synced) HIP_TRY(e, hipStreamSynchronize(c->stream));
   if (!defer) HIP_TRY(e, hipStreamSynchronize(c->stream2));
@@ -321,6 +336,8 @@ int dani_frontend_batch(dani_engine* e, int32_t sequence, const uint8_t* gray, i
   if (defer) { S->pend_desc = desc; S->pend_cap = cap; }
   S->ms[2] = ms_since(t2);
   S->ms[3] = ms_since(t0);
+  trace_mark("end");
+  trace_end();
   return DANI_OK;
 }
 

@@ -484,11 +484,14 @@ int lg_match_impl(dani_engine* e, const LgCall& call, int32_t P, int32_t in_cap,
   }
   HIP_TRY(e, hipEventRecord(c->ev_lg1, s));
   HIP_TRY(e, hipGetLastError());
+  trace_mark("lg_enqueued");
   // m0 | m1 | max0 are three rows of one block: ONE linear copy up to the end of the third row's valid part (the strided 2-D form
   // took a slower path in the runtime and sits at the very end of the call)
   HIP_TRY(e, hipMemcpyAsync(L->h_m0, L->m0, ((size_t)2 * L->ld + (size_t)doff) * 4, hipMemcpyDeviceToHost, s));
   if (call.overlap) (*call.overlap)();   // host work of the caller that can run under the forward pass
+  trace_mark("desc_moved");
   HIP_TRY(e, hipStreamSynchronize(s));
+  trace_mark("lg_synced");
   (void)hipEventElapsedTime(&c->ms[0], c->ev_lg0, c->ev_lg1);
   c->ms[4] = c->ms[0];
   t_last_ctx = c;

@@ -398,6 +398,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     c->spec_valid = false;
     if (!c->cands_enqueued || NL != 1) return DANI_OK;
     if ((rc = fetch_candidates())) return rc;
+    trace_mark("sp_candidates_on_host");
     if ((int)c->spec_sels.size() < B) c->spec_sels.resize(B);
     std::vector<char> okf(B, 1);
     host_pool().run(B, [&](int b) {
@@ -496,6 +497,7 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
     }
     if (mono_index) mono_index[b] = monoIndex;
   });
+  trace_mark("cull_quadtree_assembly_done");
   c->cands_enqueued = false;
   int status = DANI_OK;
   for (int b = 0; b < B; b++) if (frame_status[b] != DANI_OK) status = frame_status[b];
@@ -518,21 +520,32 @@ int sp_extract_impl(dani_engine* e, const SpCall& call, const uint8_t* imgs, int
                        maxn, c->d_sampled, c->d_descout, s);
   }
   HIP_TRY(e, hipEventRecord(c->ev[4], s));
+  trace_mark("desc_kernels_enqueued");
   if (desc) {   // descriptor read-back on the second stream so that it can run under the next stage's kernels
     HIP_TRY(e, hipEventRecord(c->ev_desc, s));
     HIP_TRY(e, hipStreamWaitEvent(c->stream2, c->ev_desc, 0));
     // fused call: into pinned staging (a copy into pageable memory would block this thread until it is done); the
     // caller moves it to `desc` while LightGlue runs
-    for (int b = 0; b < B; b++)
-      if (n_out[b])
-        HIP_TRY(e, hipMemcpyAsync(call.defer_desc_sync ? c->h_desc + (size_t)b * c->kcap * 256 : desc + (size_t)b * cap * 256,
-                                  c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, c->stream2));
+    if (!(call.defer_desc_sync && call.defer_desc_copies))
+      for (int b = 0; b < B; b++)
+        if (n_out[b])
+          HIP_TRY(e, hipMemcpyAsync(call.defer_desc_sync ? c->h_desc + (size_t)b * c->kcap * 256 : desc + (size_t)b * cap * 256,
+                                    c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024, hipMemcpyDeviceToHost, c->stream2));
     if (!call.defer_desc_sync) HIP_TRY(e, hipStreamSynchronize(c->stream2));
   }
   HIP_TRY(e, hipGetLastError());
   if (call.defer_desc_sync) return DANI_OK;   // the fused call synchronises (and reads the timers) after LightGlue
   HIP_TRY(e, hipStreamSynchronize(s));
   sp_read_timers(c, prof);
+  return DANI_OK;
+}
+
+// the fused call's descriptor read-back into the pinned staging buffer (SpCall::defer_desc_copies): stream2 already waits for ev_desc
+int sp_enqueue_desc_readback(dani_engine* e, Context* c, const int32_t* n_out, int B) {
+  for (int b = 0; b < B; b++)
+    if (n_out[b])
+      HIP_TRY(e, hipMemcpyAsync(c->h_desc + (size_t)b * c->kcap * 256, c->d_descout + (size_t)b * c->kcap * 256, (size_t)n_out[b] * 1024,
+                                hipMemcpyDeviceToHost, c->stream2));
   return DANI_OK;
 }
 

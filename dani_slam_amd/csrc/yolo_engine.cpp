@@ -33,6 +33,11 @@ struct YoloContext {
   uint8_t* d_img = nullptr; size_t d_img_bytes = 0;
   float* cand = nullptr; int* cand_count = nullptr;
   float* h_cand = nullptr; int* h_count = nullptr;
+  // counts + the first YOLO_CAND_FAST records of every frame as ONE contiguous block (device and pinned host): one linear copy.
+  // (hipMemcpy2DAsync of the strided [frame][15120] layout took a path whose completion reached the host ~0.1 ms after the GPU was
+  //  done -- with the GPU idle behind it.)  fast_block = [64 ints: counts][B][YOLO_CAND_FAST][8]; cand_count / h_count point at its head.
+  char* fast_block = nullptr; char* h_fast_block = nullptr;
+  float* cand_fast = nullptr; float* h_cand_fast = nullptr;
   std::vector<void*> dev_allocs, host_allocs;
   // the Detect heads of the 48x80 and 24x40 levels run on a side stream as soon as their inputs exist (model.17 / model.20),
   // under the rest of the chain, instead of at its end
@@ -286,9 +291,13 @@ int yolo_ensure(dani_engine* e, Context* c, YoloContext** out, int B, size_t img
   }
 #undef MK
   HIP_TRY(e, hipMalloc((void**)&Y->cand, (size_t)B * YOLO_CAND_CAP * 8 * 4)); Y->dev_allocs.push_back(Y->cand);
-  HIP_TRY(e, hipMalloc((void**)&Y->cand_count, (size_t)B * 4)); Y->dev_allocs.push_back(Y->cand_count);
+  const size_t count_bytes = (size_t)round_up(B, 64) * 4, fast_bytes = count_bytes + (size_t)B * YOLO_CAND_FAST * 32;
+  HIP_TRY(e, hipMalloc((void**)&Y->fast_block, fast_bytes)); Y->dev_allocs.push_back(Y->fast_block);
+  HIP_TRY(e, hipMemset(Y->fast_block, 0, fast_bytes));
+  Y->cand_count = reinterpret_cast<int*>(Y->fast_block); Y->cand_fast = reinterpret_cast<float*>(Y->fast_block + count_bytes);
   HIP_TRY(e, hipHostMalloc((void**)&Y->h_cand, (size_t)B * YOLO_CAND_CAP * 8 * 4, hipHostMallocDefault)); Y->host_allocs.push_back(Y->h_cand);
-  HIP_TRY(e, hipHostMalloc((void**)&Y->h_count, (size_t)B * 4, hipHostMallocDefault)); Y->host_allocs.push_back(Y->h_count);
+  HIP_TRY(e, hipHostMalloc((void**)&Y->h_fast_block, fast_bytes, hipHostMallocDefault)); Y->host_allocs.push_back(Y->h_fast_block);
+  Y->h_count = reinterpret_cast<int*>(Y->h_fast_block); Y->h_cand_fast = reinterpret_cast<float*>(Y->h_fast_block + count_bytes);
   Y->d_img_bytes = std::max(img_bytes, Y->d_img_bytes);
   HIP_TRY(e, hipMalloc((void**)&Y->d_img, Y->d_img_bytes)); Y->dev_allocs.push_back(Y->d_img);
   // the zero fills above ran on the null stream, which the engine's non-blocking streams do not wait for
@@ -386,7 +395,7 @@ void yolo_forward(const YoloWeights* W, YoloContext* Y, int B, float score_thres
   if (h1 && hipStreamWaitEvent(s, Y->ev_out[1], 0) != hipSuccess) side_sync = true;
   if (side_sync) { (void)hipGetLastError(); (void)hipStreamSynchronize(Y->side); }   // ordering by brute force, never a silent race
   const ActDesc* raws[3] = {&b.at("raw0"), &b.at("raw1"), &b.at("raw2")};
-  launch_yolo_decode(raws, score_thresh, Y->cand, Y->cand_count, YOLO_CAND_CAP, B, s);
+  launch_yolo_decode(raws, score_thresh, Y->cand, Y->cand_fast, YOLO_CAND_FAST, Y->cand_count, YOLO_CAND_CAP, B, s);
 }
 
 thread_local YoloContext* t_last_yolo = nullptr;
@@ -430,6 +439,7 @@ int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, i
     dimg = Y->d_img;
   }
   HIP_TRY(e, hipEventRecord(c->ev_y0, s));
+  trace_mark("yolo_first_launch");
   launch_yolo_preproc(dimg, B, W, H, stride, fbytes, Y->buf.at("in"), s);
   t_yolo_launch_ok = true;
   yolo_forward(Wt, Y, B, score_thresh, s, &call);
@@ -439,17 +449,24 @@ int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, i
   HIP_TRY(e, hipGetLastError());
   // read-back: the counts and, optimistically, the first YOLO_CAND_FAST records of every frame in one round trip;
   // a frame with more candidates than that costs a second copy
-  HIP_TRY(e, hipMemcpyAsync(Y->h_count, Y->cand_count, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(e, hipMemcpy2DAsync(Y->h_cand, (size_t)YOLO_CAND_CAP * 32, Y->cand, (size_t)YOLO_CAND_CAP * 32, (size_t)YOLO_CAND_FAST * 32, B,
-                              hipMemcpyDeviceToHost, s));
+  HIP_TRY(e, hipMemcpyAsync(Y->h_fast_block, Y->fast_block, (size_t)round_up(e->cfg.max_batch, 64) * 4 + (size_t)B * YOLO_CAND_FAST * 32, hipMemcpyDeviceToHost, s));
+  trace_mark("yolo_enqueued");
   if (call.before_sync) (*call.before_sync)();   // the caller's host work that does not need the detections
+  trace_mark("speculation_done");
   HIP_TRY(e, hipStreamSynchronize(s));
+  trace_mark("yolo_synced");
+  if (t_trace.on && t_trace.n < 40) {   // device-side duration of the chain (ev_y0 .. ev_y1, in front of the read-back), as a pseudo mark
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, c->ev_y0, c->ev_y1);
+    t_trace.label[t_trace.n] = "zz_gpu_yolo_chain_duration"; t_trace.us[t_trace.n++] = ms * 1000.0f;
+  }
   bool more = false;
   for (int b = 0; b < B; b++) {
     if (Y->h_count[b] < 0 || Y->h_count[b] > YOLO_CAND_CAP)   // more records than predictions: memory corruption, not a capacity case
       return fail(e, DANI_ERR_HIP, "frame %d: candidate counter %d outside [0, %d]", b, Y->h_count[b], YOLO_CAND_CAP);
     if (Y->h_count[b] > YOLO_CAND_FAST) {
       more = true;
+      memcpy(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->h_cand_fast + (size_t)b * YOLO_CAND_FAST * 8, (size_t)YOLO_CAND_FAST * 32);   // the frame's list, contiguous
       HIP_TRY(e, hipMemcpyAsync(Y->h_cand + ((size_t)b * YOLO_CAND_CAP + YOLO_CAND_FAST) * 8, Y->cand + ((size_t)b * YOLO_CAND_CAP + YOLO_CAND_FAST) * 8,
                                 (size_t)(Y->h_count[b] - YOLO_CAND_FAST) * 32, hipMemcpyDeviceToHost, s));
     }
@@ -457,11 +474,19 @@ int yolo_detect_impl(dani_engine* e, const YoloCall& call, const uint8_t* bgr, i
   if (more) HIP_TRY(e, hipStreamSynchronize(s));
   if (!call.alt_stream) { (void)hipEventElapsedTime(&c->ms[0], c->ev_y0, c->ev_y1); c->ms[4] = c->ms[0]; }
   int status = DANI_OK;
-  // greedy NMS is O(k n) per frame and independent across frames
-  host_pool().run(B, [&](int b) {
-    n_out[b] = yolo_nms_host(Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8, Y->h_count[b], iou_thresh, dets6 + (size_t)b * cap * 6, cap);
+  // greedy NMS is O(k n) per frame and independent across frames.  A handful of records per frame (the usual case) is done by the
+  // calling thread at once: posting eight microsecond tasks to sleeping workers cost 24 us with the GPU idle (tools/debug/host_trace.py)
+  auto nms_task = [&](int b) {
+    float* recs = Y->h_count[b] > YOLO_CAND_FAST ? Y->h_cand + (size_t)b * YOLO_CAND_CAP * 8 : Y->h_cand_fast + (size_t)b * YOLO_CAND_FAST * 8;
+    n_out[b] = yolo_nms_host(recs, Y->h_count[b], iou_thresh, dets6 + (size_t)b * cap * 6, cap);
     if (call.post && n_out[b] <= cap) (*call.post)(b, dets6 + (size_t)b * cap * 6, n_out[b]);
-  });
+  };
+  int total_records = 0;
+  for (int b = 0; b < B; b++) total_records += Y->h_count[b];
+  static const bool old_order = getenv("DANI_FE_OLD_ORDER") && atoi(getenv("DANI_FE_OLD_ORDER")) != 0;
+  if (total_records <= 256 && !old_order) { for (int b = 0; b < B; b++) nms_task(b); }
+  else host_pool().run(B, nms_task);
+  trace_mark("nms_done");
   for (int b = 0; b < B; b++)
     if (n_out[b] > cap) status = DANI_ERR_CAPACITY;
   if (status != DANI_OK) return fail(e, status, "detection capacity %d too small", cap);

@@ -114,8 +114,8 @@ struct DecodeLevels {
   size_t fs[3];
 };
 
-__global__ __launch_bounds__(64) void yolo_decode_kernel(DecodeLevels lv, float score_thresh, float* cand, int* cand_count,
-                                                         int cand_cap) {
+__global__ __launch_bounds__(64) void yolo_decode_kernel(DecodeLevels lv, float score_thresh, float* cand, float* cand_fast, int fast_cap,
+                                                         int* cand_count, int cand_cap) {
   const int level = blockIdx.y >= lv.row0[2] ? 2 : (blockIdx.y >= lv.row0[1] ? 1 : 0);
   const int ny = lv.ny[level], nx = lv.nx[level], row = blockIdx.y - lv.row0[level];
   const int x = blockIdx.x * 64 + threadIdx.x, y = row % ny, a = row / ny, b = blockIdx.z;
@@ -141,14 +141,14 @@ __global__ __launch_bounds__(64) void yolo_decode_kernel(DecodeLevels lv, float 
   const float bw = (w2 * w2) * aw, bh = (h2 * h2) * ah;
   const int slot = atomicAdd(&cand_count[b], 1);
   if (slot < cand_cap) {
-    float* o = cand + ((size_t)b * cand_cap + slot) * 8;
+    float* o = slot < fast_cap ? cand_fast + ((size_t)b * fast_cap + slot) * 8 : cand + ((size_t)b * cand_cap + slot) * 8;   // the first fast_cap records of a frame live in the contiguous read-back block
     o[0] = __int_as_float(lv.base[level] + (a * ny + y) * nx + x);
     o[1] = cx; o[2] = cy; o[3] = bw; o[4] = bh; o[5] = obj; o[6] = best; o[7] = __int_as_float(bi);
   }
 }
 
 // all three Detect levels in one launch
-void launch_yolo_decode(const ActDesc* raws[3], float score_thresh, float* cand, int* cand_count, int cand_cap, int B, hipStream_t s) {
+void launch_yolo_decode(const ActDesc* raws[3], float score_thresh, float* cand, float* cand_fast, int fast_cap, int* cand_count, int cand_cap, int B, hipStream_t s) {
   DecodeLevels lv;
   int base = 0, row = 0, maxnx = 0;
   for (int i = 0; i < 3; i++) {
@@ -158,7 +158,7 @@ void launch_yolo_decode(const ActDesc* raws[3], float score_thresh, float* cand,
     base += 3 * r.H * r.W; row += 3 * r.H;
     maxnx = r.W > maxnx ? r.W : maxnx;
   }
-  hipLaunchKernelGGL(yolo_decode_kernel, dim3((maxnx + 63) / 64, row, B), dim3(64), 0, s, lv, score_thresh, cand, cand_count, cand_cap);
+  hipLaunchKernelGGL(yolo_decode_kernel, dim3((maxnx + 63) / 64, row, B), dim3(64), 0, s, lv, score_thresh, cand, cand_fast, fast_cap, cand_count, cand_cap);
 }
 
 }  // namespace dani
